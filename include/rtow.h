@@ -1,0 +1,210 @@
+/*
+ * rtow.h — C-ABI of the MI355X path-tracing hot path.
+ *
+ * This is the drop-in boundary for ONE path of joaotavora/raytracing-one-weekend:
+ * the per-pixel sample loop of `rtweekend::render(const Scene&, const Config&)`
+ * (reference src/render.h:35, src/render.cpp:135-191).  The reference has no FFI;
+ * a maintainer would replace the body of render() below the Scene/Config boundary
+ * with: flatten the Scene into `rtow_scene_t`, call `rtow_render()`, and hand the
+ * returned per-pixel sums to the unchanged write_color()/PPM loop
+ * (src/render.cpp:11-20,182-186).  INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no C++ / torch types;
+ *   - every function returns 0 on success or a negative RTOW_E* code and never
+ *     throws or aborts across the boundary; `rtow_last_error()` gives the text
+ *     (thread-local);
+ *   - the caller owns every host pointer for the duration of the call only;
+ *   - the context owns all device memory (scene, workspace); one call in flight
+ *     per context;
+ *   - all geometry and radiance are IEEE binary64, like the reference
+ *     (src/vec3.h:6-8: vec3 = glm::dvec3).
+ */
+#ifndef RTOW_H
+#define RTOW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTOW_ABI_VERSION 1
+
+/* error codes */
+#define RTOW_OK 0
+#define RTOW_EINVAL (-1)   /* bad argument / inconsistent scene            */
+#define RTOW_ENODEV (-2)   /* no usable HIP device                         */
+#define RTOW_EHIP (-3)     /* a HIP runtime call failed                    */
+#define RTOW_ENOSCENE (-4) /* render called before a scene was uploaded    */
+#define RTOW_EEMPTY (-5)   /* scene has no primitives (reference: UB,
+                              src/render.cpp:81)                           */
+
+/* material kinds — Lambertian / Metal / Dielectric (src/common-model.h:124-151) */
+#define RTOW_MAT_LAMBERTIAN 0
+#define RTOW_MAT_METAL 1
+#define RTOW_MAT_DIELECTRIC 2
+
+/* primitive kinds — Sphere / MovingSphere / Triangle (src/oo-primitives.h:26-88) */
+#define RTOW_PRIM_SPHERE 0
+#define RTOW_PRIM_MOVING_SPHERE 1
+#define RTOW_PRIM_TRIANGLE 2
+
+/* arithmetic modes of the device path */
+#define RTOW_F64_STRICT 0 /* binary64, no FMA contraction: bit-identical to the CPU oracle */
+#define RTOW_F64_FAST 1   /* binary64, FMA contraction allowed (default for speed)         */
+
+/* closest-hit strategies */
+#define RTOW_KERNEL_AUTO 0
+#define RTOW_KERNEL_BRUTE 1 /* every ray tests every primitive (wave-uniform stream)   */
+#define RTOW_KERNEL_BVH 2   /* per-lane stack traversal of the flattened BVH            */
+
+/* Camera state: exactly the private members of the reference Camera after its
+ * constructor ran (src/common-model.h:104-112, src/common-model.cpp:136-154). */
+typedef struct rtow_camera_t {
+  double origin[3];
+  double u[3], v[3], w[3];
+  double horizontal[3];
+  double vertical[3];
+  double lower_left_corner[3];
+  double lens_radius;
+  double t0, t1;
+} rtow_camera_t;
+
+/* One material record (src/common-model.h:124-151). */
+typedef struct rtow_material_t {
+  double albedo[3]; /* Lambertian, Metal                       */
+  double fuzz;      /* Metal, Dielectric (already clamped 0..1) */
+  double ir;        /* Dielectric index of refraction           */
+  int32_t kind;     /* RTOW_MAT_*                               */
+  int32_t pad_;
+} rtow_material_t;
+
+/* Flattened scene: one packed record array per primitive class (structure of
+ * arrays across classes; each record is a small aligned block of doubles so a
+ * wave-uniform read is one scalar load and a cooperative tile load is fully
+ * coalesced).  `prim_kind/prim_index` keep the insertion order of the
+ * reference's single primitive array (src/render.h:23), which the reference
+ * BVH build depends on (src/render.cpp:73-110). */
+typedef struct rtow_scene_t {
+  rtow_camera_t camera;
+
+  int32_t n_spheres;
+  const double *sphere_geom;   /* [n_spheres][4]  cx cy cz r            */
+  const int32_t *sphere_mat;   /* [n_spheres]     material index        */
+
+  int32_t n_moving;
+  const double *moving_geom;   /* [n_moving][8]   c0xyz c1xyz r pad     */
+  const int32_t *moving_mat;   /* [n_moving]                            */
+
+  int32_t n_triangles;
+  const double *triangle_geom; /* [n_triangles][9] ax ay az bx .. cz    */
+  const int32_t *triangle_mat; /* [n_triangles]                         */
+
+  int32_t n_materials;
+  const rtow_material_t *materials;
+
+  int32_t n_prims;             /* = n_spheres + n_moving + n_triangles  */
+  const int32_t *prim_kind;    /* [n_prims] RTOW_PRIM_* in insertion order */
+  const int32_t *prim_index;   /* [n_prims] index into that class's arrays */
+} rtow_scene_t;
+
+/* Render parameters.  image_height is derived by the caller exactly as the
+ * reference does: int(image_width / aspect_ratio) (src/render.cpp:137).
+ *
+ * `nstreams` has the meaning of the reference's `nthreads`
+ * (src/render.cpp:169-185): the samples of a pixel are split into nstreams
+ * equal runs of samples_per_pixel / nstreams samples, each run is summed in
+ * sample order into its own partial image, and the partial images are added in
+ * run order.  Effective spp = samples_per_pixel / nstreams * nstreams.
+ *
+ * Random numbers are counter-based: draw d of sample s of pixel p (global
+ * row-major index, top row first) is Philox4x32-10 keyed by `seed`; the image
+ * therefore does not depend on nranks, tile_rows or on which lane traced what. */
+typedef struct rtow_config_t {
+  int32_t image_width;
+  int32_t image_height;
+  int32_t samples_per_pixel;
+  int32_t nstreams;
+  int32_t max_child_rays;
+  int32_t precision;  /* RTOW_F64_*      */
+  int32_t kernel;     /* RTOW_KERNEL_*   */
+  int32_t rank;       /* this process's share of the image: horizontal strips of */
+  int32_t nranks;     /* tile_rows rows dealt round-robin; strip t belongs to    */
+  int32_t tile_rows;  /* rank t % nranks.  nranks=1 → whole image.               */
+  uint64_t seed;
+} rtow_config_t;
+
+typedef struct rtow_stats_t {
+  uint64_t samples;      /* (pixel, sample) pairs traced by this call            */
+  uint64_t segments;     /* ray segments traced (calls of ray_color in the ref.) */
+  uint64_t prim_tests;   /* primitive hit tests                                  */
+  uint64_t node_tests;   /* BVH box tests (0 for the brute-force kernel)         */
+  double kernel_ms;      /* device time of the trace kernel (HIP events)         */
+  double total_ms;       /* device time of the whole call (all kernels)          */
+  int32_t local_rows;    /* rows of the image owned by this rank                 */
+  int32_t kernel_used;   /* RTOW_KERNEL_* actually run                           */
+} rtow_stats_t;
+
+typedef struct rtow_ctx rtow_ctx;
+
+int rtow_abi_version(void);
+const char *rtow_last_error(void);
+
+/* Bind a context to one HIP device (one process per GPU; no global state). */
+int rtow_ctx_create(int device_id, rtow_ctx **out);
+void rtow_ctx_destroy(rtow_ctx *ctx);
+
+/* Copy the scene into HBM (and build the device BVH).  The scene stays
+ * resident until the next upload or ctx destroy. */
+int rtow_scene_upload(rtow_ctx *ctx, const rtow_scene_t *scene);
+
+/* Number of image rows owned by cfg->rank, and their global row numbers
+ * (ascending) — pure host arithmetic, usable without a GPU. */
+int rtow_local_rows(const rtow_config_t *cfg);
+int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t capacity);
+
+/* Trace this rank's rows.  `d_rgb_sums` is a DEVICE pointer to
+ * local_rows*image_width*3 doubles (row-major, this rank's rows in ascending
+ * global order); it receives the per-pixel radiance SUMS over the effective spp,
+ * i.e. the reference's `global_image` (src/render.cpp:144,176-180) before
+ * write_color divides by spp.  `hip_stream` is a hipStream_t (NULL = default
+ * stream); the call enqueues work on it and returns without synchronising,
+ * unless `stats` is non-NULL, in which case it synchronises the stream and
+ * fills `stats`. */
+int rtow_render_device(rtow_ctx *ctx, const rtow_config_t *cfg, void *d_rgb_sums,
+                       void *hip_stream, rtow_stats_t *stats);
+
+/* Convenience: upload + render + copy this rank's rows to host memory. */
+int rtow_render(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,
+                double *rgb_sums_host, rtow_stats_t *stats);
+
+/* ---- host-side scene construction (no GPU needed) --------------------------
+ * C entry points over the C++ mirror of the reference's scene-build API
+ * (host/scene.h ≙ src/common-model.h, src/oo-primitives.h, src/render.h):
+ * the two scene scripts of the reference's main.cpp, flattened. */
+typedef struct rtow_host_config_t {
+  int32_t number_of_balls_sqrt; /* src/render.h:12  */
+  double aspect_ratio;          /* src/render.h:13  */
+  int32_t moving_spheres;       /* src/render.h:16  */
+} rtow_host_config_t;
+
+/* lots_of_balls() (src/main.cpp:23-83): consumes the process-global mt19937
+ * stream from its default seed, like the reference. */
+int rtow_host_scene_cover(const rtow_host_config_t *cfg, rtow_scene_t **out);
+/* foo() (src/main.cpp:85-136): triangles of the first shape of an OBJ file. */
+int rtow_host_scene_obj(const rtow_host_config_t *cfg, const char *obj_path, rtow_scene_t **out);
+void rtow_host_scene_free(rtow_scene_t *scene);
+/* Reset the host scene-construction RNG to the reference's default seed. */
+void rtow_host_rng_reset(void);
+
+/* write_color + PPM (src/render.cpp:11-20,182-186): P3 text into a malloc'ed
+ * buffer (`*out_text`, free with rtow_host_free). */
+int rtow_host_ppm(const double *rgb_sums, int32_t width, int32_t height, int32_t spp_effective,
+                  char **out_text, uint64_t *out_len);
+void rtow_host_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTOW_H */

@@ -1,0 +1,283 @@
+"""ctypes view of the C-ABI in include/rtow.h (librtow.so).
+
+Plumbing only: it mirrors the structs, loads the in-tree shared library and adds
+thin helpers for device buffers (torch is used for device memory, streams and
+torch.distributed — not for any of the rendering arithmetic).
+
+There is no CPU fallback here by design: if librtow.so is missing or no HIP
+device is usable the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO_ROOT = PKG_DIR.parent
+LIB_PATH = PKG_DIR / "librtow.so"
+
+RTOW_ABI_VERSION = 1
+RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY = 0, -1, -2, -3, -4, -5
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
+PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
+F64_STRICT, F64_FAST = 0, 1
+KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH = 0, 1, 2
+
+d3 = C.c_double * 3
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+
+
+class Camera(C.Structure):
+    _fields_ = [
+        ("origin", d3), ("u", d3), ("v", d3), ("w", d3),
+        ("horizontal", d3), ("vertical", d3), ("lower_left_corner", d3),
+        ("lens_radius", C.c_double), ("t0", C.c_double), ("t1", C.c_double),
+    ]
+
+
+class Material(C.Structure):
+    _fields_ = [
+        ("albedo", d3), ("fuzz", C.c_double), ("ir", C.c_double),
+        ("kind", C.c_int32), ("pad_", C.c_int32),
+    ]
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("camera", Camera),
+        ("n_spheres", C.c_int32), ("sphere_geom", _pd), ("sphere_mat", _pi),
+        ("n_moving", C.c_int32), ("moving_geom", _pd), ("moving_mat", _pi),
+        ("n_triangles", C.c_int32), ("triangle_geom", _pd), ("triangle_mat", _pi),
+        ("n_materials", C.c_int32), ("materials", C.POINTER(Material)),
+        ("n_prims", C.c_int32), ("prim_kind", _pi), ("prim_index", _pi),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("image_width", C.c_int32), ("image_height", C.c_int32),
+        ("samples_per_pixel", C.c_int32), ("nstreams", C.c_int32),
+        ("max_child_rays", C.c_int32), ("precision", C.c_int32), ("kernel", C.c_int32),
+        ("rank", C.c_int32), ("nranks", C.c_int32), ("tile_rows", C.c_int32),
+        ("seed", C.c_uint64),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("samples", C.c_uint64), ("segments", C.c_uint64),
+        ("prim_tests", C.c_uint64), ("node_tests", C.c_uint64),
+        ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+        ("local_rows", C.c_int32), ("kernel_used", C.c_int32),
+    ]
+
+
+class HostConfig(C.Structure):
+    _fields_ = [
+        ("number_of_balls_sqrt", C.c_int32), ("aspect_ratio", C.c_double),
+        ("moving_spheres", C.c_int32),
+    ]
+
+
+# every symbol include/rtow.h declares
+EXPORTS = [
+    "rtow_abi_version", "rtow_last_error", "rtow_ctx_create", "rtow_ctx_destroy",
+    "rtow_scene_upload", "rtow_local_rows", "rtow_local_row_list", "rtow_render_device",
+    "rtow_render", "rtow_host_scene_cover", "rtow_host_scene_obj", "rtow_host_scene_free",
+    "rtow_host_rng_reset", "rtow_host_ppm", "rtow_host_free",
+]
+
+
+class RtowError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load librtow.so (built in-tree by __graft_entry__.build / make)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RtowError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                        " (there is no CPU fallback)")
+    L = C.CDLL(str(LIB_PATH))
+    L.rtow_abi_version.restype = C.c_int
+    L.rtow_last_error.restype = C.c_char_p
+    L.rtow_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.rtow_ctx_destroy.argtypes = [C.c_void_p]
+    L.rtow_ctx_destroy.restype = None
+    L.rtow_scene_upload.argtypes = [C.c_void_p, C.POINTER(Scene)]
+    L.rtow_local_rows.argtypes = [C.POINTER(Config)]
+    L.rtow_local_row_list.argtypes = [C.POINTER(Config), _pi, C.c_int32]
+    L.rtow_render_device.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.c_void_p,
+                                     C.POINTER(Stats)]
+    L.rtow_render.argtypes = [C.c_void_p, C.POINTER(Scene), C.POINTER(Config), _pd,
+                              C.POINTER(Stats)]
+    L.rtow_host_scene_cover.argtypes = [C.POINTER(HostConfig), C.POINTER(C.POINTER(Scene))]
+    L.rtow_host_scene_obj.argtypes = [C.POINTER(HostConfig), C.c_char_p,
+                                      C.POINTER(C.POINTER(Scene))]
+    L.rtow_host_scene_free.argtypes = [C.POINTER(Scene)]
+    L.rtow_host_scene_free.restype = None
+    L.rtow_host_rng_reset.restype = None
+    L.rtow_host_ppm.argtypes = [_pd, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p),
+                                C.POINTER(C.c_uint64)]
+    L.rtow_host_free.argtypes = [C.c_void_p]
+    L.rtow_host_free.restype = None
+    if L.rtow_abi_version() != RTOW_ABI_VERSION:
+        raise RtowError("librtow.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "rtow"):
+    if rc != 0:
+        msg = lib().rtow_last_error()
+        raise RtowError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def image_height(width: int, aspect_ratio: float) -> int:
+    """int(image_width / aspect_ratio) — reference src/render.cpp:137."""
+    return int(width / aspect_ratio)
+
+
+def make_config(width, height, spp, nstreams=1, max_child_rays=50, seed=1, precision=F64_FAST,
+                kernel=KERNEL_AUTO, rank=0, nranks=1, tile_rows=8) -> Config:
+    return Config(width, height, spp, nstreams, max_child_rays, precision, kernel, rank, nranks,
+                  tile_rows, seed)
+
+
+def spp_effective(cfg: Config) -> int:
+    """samples_per_pixel / nthreads * nthreads — reference src/render.cpp:185."""
+    return cfg.samples_per_pixel // cfg.nstreams * cfg.nstreams
+
+
+def local_rows(cfg: Config):
+    L = lib()
+    n = L.rtow_local_rows(C.byref(cfg))
+    if n < 0:
+        check(n, "rtow_local_rows")
+    buf = (C.c_int32 * max(n, 1))()
+    got = L.rtow_local_row_list(C.byref(cfg), buf, n)
+    if got < 0:
+        check(got, "rtow_local_row_list")
+    return list(buf[:n])
+
+
+class HostScene:
+    """A flattened scene built by the product's host-side scene scripts."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    @property
+    def c(self) -> Scene:
+        return self.ptr.contents
+
+    @classmethod
+    def cover(cls, nsqrt=11, aspect=1.5, moving=False, reset_rng=True):
+        L = lib()
+        if reset_rng:
+            L.rtow_host_rng_reset()
+        hc = HostConfig(nsqrt, aspect, int(moving))
+        out = C.POINTER(Scene)()
+        check(L.rtow_host_scene_cover(C.byref(hc), C.byref(out)), "rtow_host_scene_cover")
+        return cls(out)
+
+    @classmethod
+    def obj(cls, path, aspect=16.0 / 9.0, reset_rng=True):
+        L = lib()
+        if reset_rng:
+            L.rtow_host_rng_reset()
+        hc = HostConfig(0, aspect, 0)
+        out = C.POINTER(Scene)()
+        check(L.rtow_host_scene_obj(C.byref(hc), str(path).encode(), C.byref(out)),
+              "rtow_host_scene_obj")
+        return cls(out)
+
+    def close(self):
+        if self.ptr:
+            lib().rtow_host_scene_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ppm_text(rgb_sums, width, height, spp_eff) -> bytes:
+    """write_color + P3 framing (reference src/render.cpp:11-20,182-186)."""
+    import numpy as np
+
+    a = np.ascontiguousarray(rgb_sums, dtype=np.float64)
+    assert a.size == width * height * 3
+    txt = C.c_char_p()
+    n = C.c_uint64()
+    L = lib()
+    check(L.rtow_host_ppm(a.ctypes.data_as(_pd), width, height, spp_eff, C.byref(txt), C.byref(n)),
+          "rtow_host_ppm")
+    try:
+        return C.string_at(txt, n.value)
+    finally:
+        L.rtow_host_free(txt)
+
+
+class Context:
+    """One HIP device (one process per GPU)."""
+
+    def __init__(self, device_id: int = 0):
+        self._h = C.c_void_p()
+        check(lib().rtow_ctx_create(device_id, C.byref(self._h)), "rtow_ctx_create")
+        self.device_id = device_id
+
+    def upload(self, scene):
+        s = scene.c if isinstance(scene, HostScene) else scene
+        check(lib().rtow_scene_upload(self._h, C.byref(s)), "rtow_scene_upload")
+
+    def render_device(self, cfg: Config, d_ptr: int, stream: int = 0, want_stats=False):
+        st = Stats() if want_stats else None
+        check(lib().rtow_render_device(self._h, C.byref(cfg), C.c_void_p(d_ptr),
+                                       C.c_void_p(stream), C.byref(st) if st is not None else None),
+              "rtow_render_device")
+        return st
+
+    def render(self, scene, cfg: Config):
+        """Upload + render + D2H: returns (numpy [rows, W, 3] float64 sums, Stats)."""
+        import numpy as np
+
+        s = scene.c if isinstance(scene, HostScene) else scene
+        rows = lib().rtow_local_rows(C.byref(cfg))
+        if rows < 0:
+            check(rows, "rtow_local_rows")
+        out = np.zeros((rows, cfg.image_width, 3), dtype=np.float64)
+        st = Stats()
+        check(lib().rtow_render(self._h, C.byref(s), C.byref(cfg), out.ctypes.data_as(_pd),
+                                C.byref(st)), "rtow_render")
+        return out, st
+
+    def close(self):
+        if self._h:
+            lib().rtow_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def have_gpu() -> bool:
+    """True when a HIP device can be bound (used by tests to choose markers only)."""
+    try:
+        c = Context(0)
+        c.close()
+        return True
+    except Exception:
+        return False
