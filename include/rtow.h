@@ -175,6 +175,13 @@ int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t cap
 int rtow_render_device(rtow_ctx *ctx, const rtow_config_t *cfg, void *d_rgb_sums,
                        void *hip_stream, rtow_stats_t *stats);
 
+/* Every rtow_render_device call brackets its trace-kernel launch with a HIP event
+ * pair on the launch stream (no host sync).  This collects the device time of
+ * all launches since the previous collect (it waits for them) and resets the
+ * ring: `*kernel_ms_sum` = total trace-kernel milliseconds, `*launches` = how
+ * many launches that covers (the ring keeps the first 256 per collect). */
+int rtow_profile_collect(rtow_ctx *ctx, double *kernel_ms_sum, int32_t *launches);
+
 /* Convenience: upload + render + copy this rank's rows to host memory. */
 int rtow_render(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,
                 double *rgb_sums_host, rtow_stats_t *stats);

@@ -1,0 +1,245 @@
+// rtow_bvh.h — host build of the device BVH (binned SAH, BVH2, DFS layout).
+//
+// This is NOT the reference's tree (src/render.cpp:73-110 splits at the median
+// of one heuristic axis and unions every leaf box with the origin, so it culls
+// poorly — SURVEY.md §3.2).  The closest hit does not depend on the tree: any
+// conservative BVH returns the same (t, primitive) as testing every primitive,
+// so the device is free to use a better one.  Boxes are padded so that rounding
+// in the slab test can never cull a primitive the exact hit test would accept.
+//
+// Layout: node 0 is the root; the two children of an inner node are adjacent
+// (left odd, right = left+1 even), so sibling(i) = i odd ? i+1 : i-1.
+//   box [n][6]  : min xyz, max xyz
+//   link[n][4]  : inner: {left child, 0, parent, 0}; leaf: {first, count, parent, 0}
+//   prim[]      : class-major primitive ids, leaf ranges contiguous
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace rtow {
+
+struct HostBvh {
+  std::vector<double> box;
+  std::vector<int32_t> link;
+  std::vector<int32_t> prim;
+  int depth = 0;
+};
+
+namespace bvh_detail {
+
+struct Box {
+  double mn[3], mx[3];
+  void reset() {
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = INFINITY;
+      mx[k] = -INFINITY;
+    }
+  }
+  void grow(const Box &b) {
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = std::min(mn[k], b.mn[k]);
+      mx[k] = std::max(mx[k], b.mx[k]);
+    }
+  }
+  double half_area() const {
+    double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (!(dx >= 0) || !(dy >= 0) || !(dz >= 0)) return 0.0;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Builder {
+  std::vector<Box> pb;        // primitive bounds
+  std::vector<double> cen;    // centroids [n][3]
+  std::vector<int32_t> order; // permutation being partitioned
+  HostBvh *out;
+  static constexpr int kBins = 16;
+  static constexpr int kLeafMax = 4;
+  static constexpr int kMaxDepth = 56;
+
+  void set_node(int idx, const Box &b, int a, int c, int parent) {
+    for (int k = 0; k < 3; ++k) {
+      out->box[(size_t)idx * 6 + k] = b.mn[k];
+      out->box[(size_t)idx * 6 + 3 + k] = b.mx[k];
+    }
+    out->link[(size_t)idx * 4 + 0] = a;
+    out->link[(size_t)idx * 4 + 1] = c;
+    out->link[(size_t)idx * 4 + 2] = parent;
+    out->link[(size_t)idx * 4 + 3] = 0;
+  }
+
+  void build(int idx, int lo, int hi, int parent, int depth) {
+    out->depth = std::max(out->depth, depth);
+    Box b, cb;
+    b.reset();
+    cb.reset();
+    for (int i = lo; i < hi; ++i) {
+      const int p = order[i];
+      b.grow(pb[p]);
+      for (int k = 0; k < 3; ++k) {
+        cb.mn[k] = std::min(cb.mn[k], cen[(size_t)p * 3 + k]);
+        cb.mx[k] = std::max(cb.mx[k], cen[(size_t)p * 3 + k]);
+      }
+    }
+    const int n = hi - lo;
+    auto make_leaf = [&]() {
+      const int first = (int)out->prim.size();
+      for (int i = lo; i < hi; ++i) out->prim.push_back(order[i]);
+      set_node(idx, b, first, n, parent);
+    };
+    if (n <= 1 || (depth >= kMaxDepth && n <= 64)) {
+      make_leaf();
+      return;
+    }
+    // binned SAH over the three axes
+    int best_axis = -1, best_split = -1;
+    double best_cost = INFINITY;
+    for (int ax = 0; ax < 3; ++ax) {
+      const double c0 = cb.mn[ax], c1 = cb.mx[ax];
+      if (!(c1 > c0)) continue;
+      Box bins[kBins];
+      int cnt[kBins];
+      for (int k = 0; k < kBins; ++k) {
+        bins[k].reset();
+        cnt[k] = 0;
+      }
+      const double scale = kBins / (c1 - c0);
+      for (int i = lo; i < hi; ++i) {
+        const int p = order[i];
+        int bi = (int)((cen[(size_t)p * 3 + ax] - c0) * scale);
+        bi = std::min(std::max(bi, 0), kBins - 1);
+        bins[bi].grow(pb[p]);
+        cnt[bi]++;
+      }
+      double right_area[kBins];
+      int right_cnt[kBins];
+      Box acc;
+      acc.reset();
+      int c = 0;
+      for (int k = kBins - 1; k >= 1; --k) {
+        acc.grow(bins[k]);
+        c += cnt[k];
+        right_area[k] = acc.half_area();
+        right_cnt[k] = c;
+      }
+      acc.reset();
+      c = 0;
+      for (int k = 0; k < kBins - 1; ++k) {
+        acc.grow(bins[k]);
+        c += cnt[k];
+        if (c == 0 || right_cnt[k + 1] == 0) continue;
+        const double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_axis = ax;
+          best_split = k;
+        }
+      }
+    }
+    int mid = -1;
+    if (best_axis >= 0) {
+      const double leaf_cost = b.half_area() * n;
+      if (n <= kLeafMax && best_cost >= leaf_cost) {
+        make_leaf();
+        return;
+      }
+      const double c0 = cb.mn[best_axis], c1 = cb.mx[best_axis];
+      const double scale = kBins / (c1 - c0);
+      auto it = std::partition(order.begin() + lo, order.begin() + hi, [&](int p) {
+        int bi = (int)((cen[(size_t)p * 3 + best_axis] - c0) * scale);
+        bi = std::min(std::max(bi, 0), kBins - 1);
+        return bi <= best_split;
+      });
+      mid = (int)(it - order.begin());
+    }
+    if (mid <= lo || mid >= hi || depth >= kMaxDepth - 8) {
+      // degenerate (coincident centroids) or too deep: median split on the widest axis
+      if (best_axis < 0 && n <= kLeafMax) {
+        make_leaf();
+        return;
+      }
+      int ax = 0;
+      for (int k = 1; k < 3; ++k)
+        if (cb.mx[k] - cb.mn[k] > cb.mx[ax] - cb.mn[ax]) ax = k;
+      mid = lo + n / 2;
+      std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](int p, int q) {
+        return cen[(size_t)p * 3 + ax] < cen[(size_t)q * 3 + ax];
+      });
+    }
+    const int left = (int)(out->link.size() / 4);
+    out->link.resize((size_t)(left + 2) * 4);
+    out->box.resize((size_t)(left + 2) * 6);
+    set_node(idx, b, left, 0, parent);
+    build(left, lo, mid, idx, depth + 1);
+    build(left + 1, mid, hi, idx, depth + 1);
+  }
+};
+
+inline void pad_box(Box &b) {
+  // slack ≫ any rounding in the f64 slab test, ≪ any visible geometry
+  for (int k = 0; k < 3; ++k) {
+    const double ext = std::max(std::fabs(b.mn[k]), std::fabs(b.mx[k]));
+    const double pad = 1e-9 * (1.0 + ext);
+    b.mn[k] -= pad;
+    b.mx[k] += pad;
+  }
+}
+
+}  // namespace bvh_detail
+
+// sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
+inline void build_bvh(const std::vector<double> &sph, const std::vector<double> &sph_r,
+                      const std::vector<double> &mov, const std::vector<double> &tri, HostBvh &out) {
+  using namespace bvh_detail;
+  const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
+  const int n = ns + nm + nt;
+  Builder B;
+  B.out = &out;
+  B.pb.resize(n);
+  B.cen.resize((size_t)n * 3);
+  for (int i = 0; i < ns; ++i) {
+    Box &b = B.pb[i];
+    const double r = std::fabs(sph_r[i]);
+    for (int k = 0; k < 3; ++k) {
+      b.mn[k] = sph[(size_t)i * 4 + k] - r;
+      b.mx[k] = sph[(size_t)i * 4 + k] + r;
+    }
+  }
+  for (int i = 0; i < nm; ++i) {
+    // centre moves along c0 + time*delta; the shutter interval is [t0,t1] ⊆ [0,1] in the
+    // reference's scenes — bound over [0,1] widened by the same amount again for safety
+    Box &b = B.pb[ns + i];
+    const double *m = &mov[(size_t)i * 8];
+    const double r = std::fabs(m[7]);
+    for (int k = 0; k < 3; ++k) {
+      const double a0 = m[k] - 1.0 * m[3 + k], a1 = m[k] + 2.0 * m[3 + k];
+      b.mn[k] = std::min(a0, a1) - r;
+      b.mx[k] = std::max(a0, a1) + r;
+    }
+  }
+  for (int i = 0; i < nt; ++i) {
+    Box &b = B.pb[ns + nm + i];
+    const double *t = &tri[(size_t)i * 12];
+    for (int k = 0; k < 3; ++k) {
+      const double a = t[k], bb = t[k] + t[3 + k], c = t[k] + t[6 + k];
+      b.mn[k] = std::min(a, std::min(bb, c));
+      b.mx[k] = std::max(a, std::max(bb, c));
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    pad_box(B.pb[i]);
+    for (int k = 0; k < 3; ++k) B.cen[(size_t)i * 3 + k] = 0.5 * (B.pb[i].mn[k] + B.pb[i].mx[k]);
+  }
+  B.order.resize(n);
+  for (int i = 0; i < n; ++i) B.order[i] = i;
+  out.box.assign(6, 0.0);
+  out.link.assign(4, 0);
+  out.prim.clear();
+  out.prim.reserve(n);
+  out.depth = 0;
+  if (n > 0) B.build(0, 0, n, -1, 0);
+}
+
+}  // namespace rtow

@@ -1,0 +1,477 @@
+// rtow_capi.cpp — the C-ABI shim of include/rtow.h over the HIP kernels.
+//
+// One context = one HIP device.  The context owns the flattened scene in HBM,
+// the workspace (per-stream partial images, per-lane path stack, counters) and a
+// ring of event pairs that time every trace-kernel launch without a host sync.
+// There is no CPU fallback: without a usable HIP device every entry point fails
+// with RTOW_ENODEV / RTOW_EHIP.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtow.h"
+#include "rtow_bvh.h"
+#include "rtow_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(RTOW_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+constexpr int kBlock = 256;
+constexpr int kEventRing = 256;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return RTOW_OK;
+    if (p) {
+      HIPCHK(hipFree(p));
+      p = nullptr;
+      bytes = 0;
+    }
+    size_t want = need + need / 8 + 256;
+    HIPCHK(hipMalloc(&p, want));
+    bytes = want;
+    return RTOW_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+template <class T>
+int upload(DevBuf &b, const std::vector<T> &v) {
+  size_t n = v.size() * sizeof(T);
+  int rc = b.ensure(n ? n : sizeof(T));
+  if (rc) return rc;
+  if (n) HIPCHK(hipMemcpy(b.p, v.data(), n, hipMemcpyHostToDevice));
+  return RTOW_OK;
+}
+
+}  // namespace
+
+struct rtow_ctx {
+  int device = 0;
+  int num_cus = 0;
+  bool have_scene = false;
+  rtow::DevScene ds{};
+  rtow::DevCamera cam{};
+  int n_prims = 0;
+  // scene buffers
+  DevBuf sph, sph_r, mov, tri, prim_mat, mats, bvh_box, bvh_link, bvh_prim;
+  // workspace
+  DevBuf partials, stack, counters;
+  // occupancy (blocks per CU) per precision, filled lazily
+  int occ[2] = {0, 0};
+  // profiling ring: event pairs around each trace-kernel launch since the last collect
+  hipEvent_t ev[kEventRing][2];
+  bool ev_ready = false;
+  int ev_count = 0;
+  hipEvent_t call_ev[2];
+  // pinned host mirror of the counters for stats
+  unsigned long long *h_counters = nullptr;
+};
+
+extern "C" {
+
+int rtow_abi_version(void) { return RTOW_ABI_VERSION; }
+
+const char *rtow_last_error(void) { return g_err.c_str(); }
+
+int rtow_ctx_create(int device_id, rtow_ctx **out) {
+  if (!out) return fail(RTOW_EINVAL, "rtow_ctx_create: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(RTOW_ENODEV, "no HIP device (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(RTOW_ENODEV, "device %d out of range [0,%d)", device_id, n);
+  HIPCHK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_id));
+  rtow_ctx *c = new rtow_ctx();
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount;
+  for (int i = 0; i < kEventRing; ++i)
+    for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreate(&c->ev[i][k]));
+  for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreate(&c->call_ev[k]));
+  c->ev_ready = true;
+  HIPCHK(hipHostMalloc((void **)&c->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+  *out = c;
+  return RTOW_OK;
+}
+
+void rtow_ctx_destroy(rtow_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->bvh_box,
+                    &c->bvh_link, &c->bvh_prim, &c->partials, &c->stack, &c->counters})
+    b->release();
+  if (c->ev_ready) {
+    for (int i = 0; i < kEventRing; ++i)
+      for (int k = 0; k < 2; ++k) (void)hipEventDestroy(c->ev[i][k]);
+    for (int k = 0; k < 2; ++k) (void)hipEventDestroy(c->call_ev[k]);
+  }
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  delete c;
+}
+
+static int validate_scene(const rtow_scene_t *s) {
+  if (!s) return fail(RTOW_EINVAL, "scene is NULL");
+  if (s->n_spheres < 0 || s->n_moving < 0 || s->n_triangles < 0 || s->n_materials < 0)
+    return fail(RTOW_EINVAL, "negative count in scene");
+  const long long np = (long long)s->n_spheres + s->n_moving + s->n_triangles;
+  if (np == 0) return fail(RTOW_EEMPTY, "scene has no primitives");
+  if (s->n_prims != np) return fail(RTOW_EINVAL, "n_prims (%d) != sum of classes (%lld)", s->n_prims, np);
+  if (s->n_materials == 0 || !s->materials) return fail(RTOW_EINVAL, "scene has no materials");
+  if ((s->n_spheres && (!s->sphere_geom || !s->sphere_mat)) ||
+      (s->n_moving && (!s->moving_geom || !s->moving_mat)) ||
+      (s->n_triangles && (!s->triangle_geom || !s->triangle_mat)))
+    return fail(RTOW_EINVAL, "NULL geometry/material array");
+  auto chk = [&](const int32_t *m, int n) {
+    for (int i = 0; i < n; ++i)
+      if (m[i] < 0 || m[i] >= s->n_materials) return false;
+    return true;
+  };
+  if (!chk(s->sphere_mat, s->n_spheres) || !chk(s->moving_mat, s->n_moving) ||
+      !chk(s->triangle_mat, s->n_triangles))
+    return fail(RTOW_EINVAL, "material index out of range");
+  for (int i = 0; i < s->n_materials; ++i)
+    if (s->materials[i].kind < 0 || s->materials[i].kind > 2)
+      return fail(RTOW_EINVAL, "material %d has unknown kind %d", i, s->materials[i].kind);
+  return RTOW_OK;
+}
+
+int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  int rc = validate_scene(s);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());
+  c->have_scene = false;
+
+  // Ray-independent terms, computed with the reference's operations (this file is
+  // built with -ffp-contract=off, so each is one IEEE operation, as on the CPU).
+  const int ns = s->n_spheres, nm = s->n_moving, nt = s->n_triangles;
+  std::vector<double> sph((size_t)ns * 4), sph_r(ns), mov((size_t)nm * 8), tri((size_t)nt * 12);
+  for (int i = 0; i < ns; ++i) {
+    const double *g = s->sphere_geom + 4 * (size_t)i;
+    sph[4 * (size_t)i + 0] = g[0];
+    sph[4 * (size_t)i + 1] = g[1];
+    sph[4 * (size_t)i + 2] = g[2];
+    sph[4 * (size_t)i + 3] = g[3] * g[3];  // radius * radius, src/common-model.cpp:73
+    sph_r[i] = g[3];
+  }
+  for (int i = 0; i < nm; ++i) {
+    const double *g = s->moving_geom + 8 * (size_t)i;
+    double *d = &mov[8 * (size_t)i];
+    d[0] = g[0];
+    d[1] = g[1];
+    d[2] = g[2];
+    d[3] = g[3] - g[0];  // center1 - center0, src/oo-primitives.h:65
+    d[4] = g[4] - g[1];
+    d[5] = g[5] - g[2];
+    d[6] = g[6] * g[6];
+    d[7] = g[6];
+  }
+  for (int i = 0; i < nt; ++i) {
+    const double *g = s->triangle_geom + 9 * (size_t)i;
+    double *d = &tri[12 * (size_t)i];
+    const double e1[3] = {g[3] - g[0], g[4] - g[1], g[5] - g[2]};  // b - a
+    const double e2[3] = {g[6] - g[0], g[7] - g[1], g[8] - g[2]};  // c - a
+    d[0] = g[0];
+    d[1] = g[1];
+    d[2] = g[2];
+    for (int k = 0; k < 3; ++k) {
+      d[3 + k] = e1[k];
+      d[6 + k] = e2[k];
+    }
+    // n = cross(e1, e2), src/common-model.cpp:108
+    d[9] = e1[1] * e2[2] - e2[1] * e1[2];
+    d[10] = e1[2] * e2[0] - e2[2] * e1[0];
+    d[11] = e1[0] * e2[1] - e2[0] * e1[1];
+  }
+  std::vector<int32_t> pmat((size_t)ns + nm + nt);
+  for (int i = 0; i < ns; ++i) pmat[i] = s->sphere_mat[i];
+  for (int i = 0; i < nm; ++i) pmat[(size_t)ns + i] = s->moving_mat[i];
+  for (int i = 0; i < nt; ++i) pmat[(size_t)ns + nm + i] = s->triangle_mat[i];
+  std::vector<rtow::DevMaterial> mats(s->n_materials);
+  for (int i = 0; i < s->n_materials; ++i) {
+    const rtow_material_t &m = s->materials[i];
+    rtow::DevMaterial &d = mats[i];
+    std::memset(&d, 0, sizeof d);
+    const bool diel = m.kind == RTOW_MAT_DIELECTRIC;  // attenuation {1,1,1}, common-model.cpp:61
+    for (int k = 0; k < 3; ++k) d.att[k] = diel ? 1.0 : m.albedo[k];
+    d.fuzz = m.kind == RTOW_MAT_LAMBERTIAN ? 0.0 : m.fuzz;
+    d.ir = m.ir;
+    d.kind = m.kind;
+  }
+
+  // device BVH over the same records
+  rtow::HostBvh bvh;
+  rtow::build_bvh(sph, sph_r, mov, tri, bvh);
+
+  if ((rc = upload(c->sph, sph)) || (rc = upload(c->sph_r, sph_r)) || (rc = upload(c->mov, mov)) ||
+      (rc = upload(c->tri, tri)) || (rc = upload(c->prim_mat, pmat)) || (rc = upload(c->mats, mats)) ||
+      (rc = upload(c->bvh_box, bvh.box)) || (rc = upload(c->bvh_link, bvh.link)) ||
+      (rc = upload(c->bvh_prim, bvh.prim)))
+    return rc;
+
+  rtow::DevScene &ds = c->ds;
+  ds.sph = (const double *)c->sph.p;
+  ds.sph_r = (const double *)c->sph_r.p;
+  ds.mov = (const double *)c->mov.p;
+  ds.tri = (const double *)c->tri.p;
+  ds.prim_mat = (const int32_t *)c->prim_mat.p;
+  ds.mats = (const rtow::DevMaterial *)c->mats.p;
+  ds.n_sph = ns;
+  ds.n_mov = nm;
+  ds.n_tri = nt;
+  ds.n_mats = s->n_materials;
+  ds.bvh_box = (const double *)c->bvh_box.p;
+  ds.bvh_link = (const int32_t *)c->bvh_link.p;
+  ds.bvh_prim = (const int32_t *)c->bvh_prim.p;
+  ds.n_nodes = (int32_t)(bvh.link.size() / 4);
+  c->n_prims = ns + nm + nt;
+
+  const rtow_camera_t &k = s->camera;
+  rtow::DevCamera &dc = c->cam;
+  for (int i = 0; i < 3; ++i) {
+    dc.origin[i] = k.origin[i];
+    dc.u[i] = k.u[i];
+    dc.v[i] = k.v[i];
+    dc.horizontal[i] = k.horizontal[i];
+    dc.vertical[i] = k.vertical[i];
+    dc.llc[i] = k.lower_left_corner[i];
+  }
+  dc.lens_radius = k.lens_radius;
+  dc.t0 = k.t0;
+  dc.t1 = k.t1;
+  c->have_scene = true;
+  return RTOW_OK;
+}
+
+static int validate_cfg(const rtow_config_t *cfg) {
+  if (!cfg) return fail(RTOW_EINVAL, "config is NULL");
+  if (cfg->image_width <= 0 || cfg->image_height <= 0)
+    return fail(RTOW_EINVAL, "image size %dx%d", cfg->image_width, cfg->image_height);
+  if (cfg->nstreams <= 0) return fail(RTOW_EINVAL, "nstreams must be >= 1");
+  if (cfg->samples_per_pixel < 0 || cfg->max_child_rays < 0)
+    return fail(RTOW_EINVAL, "negative samples_per_pixel / max_child_rays");
+  if (cfg->nranks <= 0 || cfg->rank < 0 || cfg->rank >= cfg->nranks)
+    return fail(RTOW_EINVAL, "rank %d of %d", cfg->rank, cfg->nranks);
+  if (cfg->tile_rows <= 0) return fail(RTOW_EINVAL, "tile_rows must be >= 1");
+  if (cfg->precision != RTOW_F64_STRICT && cfg->precision != RTOW_F64_FAST)
+    return fail(RTOW_EINVAL, "unknown precision %d", cfg->precision);
+  if (cfg->kernel < RTOW_KERNEL_AUTO || cfg->kernel > RTOW_KERNEL_BVH)
+    return fail(RTOW_EINVAL, "unknown kernel %d", cfg->kernel);
+  if ((long long)cfg->image_width * cfg->image_height > 0x7fffffffLL)
+    return fail(RTOW_EINVAL, "image too large");
+  return RTOW_OK;
+}
+
+int rtow_local_rows(const rtow_config_t *cfg) {
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  int rows = 0;
+  for (int i = 0; i < cfg->image_height; ++i)
+    if ((i / cfg->tile_rows) % cfg->nranks == cfg->rank) ++rows;
+  return rows;
+}
+
+int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t capacity) {
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  if (!rows_out && capacity > 0) return fail(RTOW_EINVAL, "rows_out is NULL");
+  int n = 0;
+  for (int i = 0; i < cfg->image_height; ++i)
+    if ((i / cfg->tile_rows) % cfg->nranks == cfg->rank) {
+      if (n < capacity) rows_out[n] = i;
+      ++n;
+    }
+  return n;
+}
+
+int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
+                       rtow_stats_t *stats) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  if (!c->have_scene) return fail(RTOW_ENOSCENE, "no scene uploaded");
+  if (!d_rgb_sums) return fail(RTOW_EINVAL, "d_rgb_sums is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+
+  const int rows = rtow_local_rows(cfg);
+  const int spt = cfg->samples_per_pixel / cfg->nstreams;  // src/render.cpp:174
+  const unsigned long long npix = (unsigned long long)rows * cfg->image_width;
+  const unsigned long long n_items = npix * (unsigned long long)cfg->nstreams;
+  if (n_items > 0xfffffff0ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
+
+  int kernel = cfg->kernel;
+  if (kernel == RTOW_KERNEL_AUTO) kernel = RTOW_KERNEL_BRUTE;
+  const bool strict = cfg->precision == RTOW_F64_STRICT;
+
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->local_rows = rows;
+    stats->kernel_used = kernel;
+  }
+  if (npix == 0) return RTOW_OK;
+
+  // grid: as many 256-lane blocks as stay resident, but no more than there are items
+  int &occ = c->occ[strict ? 0 : 1];
+  if (occ <= 0) {
+    occ = strict ? rtow::trace_occupancy_strict(kernel, kBlock) : rtow::trace_occupancy_fast(kernel, kBlock);
+    if (occ <= 0) return fail(RTOW_EHIP, "occupancy query failed");
+    if (occ > 8) occ = 8;
+  }
+  long long grid = (long long)c->num_cus * occ;
+  const long long need_blocks = (long long)((n_items + kBlock - 1) / kBlock);
+  if (grid > need_blocks) grid = need_blocks;
+  if (grid < 1) grid = 1;
+  const unsigned long long n_lanes = (unsigned long long)grid * kBlock;
+
+  const size_t depth_slots = (size_t)(cfg->max_child_rays > 0 ? cfg->max_child_rays : 1);
+  if ((rc = c->partials.ensure((size_t)n_items * 3 * sizeof(double))) ||
+      (rc = c->stack.ensure(depth_slots * (size_t)n_lanes * sizeof(uint32_t))) ||
+      (rc = c->counters.ensure(4 * sizeof(unsigned long long))))
+    return rc;
+
+  rtow::TraceParams P;
+  std::memset(&P, 0, sizeof P);
+  P.sc = c->ds;
+  P.cam = c->cam;
+  P.W = cfg->image_width;
+  P.H = cfg->image_height;
+  P.spt = spt;
+  P.nstreams = cfg->nstreams;
+  P.max_child_rays = cfg->max_child_rays;
+  P.rank = cfg->rank;
+  P.nranks = cfg->nranks;
+  P.tile_rows = cfg->tile_rows;
+  P.local_rows = rows;
+  P.seed_lo = (uint32_t)cfg->seed;
+  P.seed_hi = (uint32_t)(cfg->seed >> 32);
+  P.n_items = (uint32_t)n_items;
+  P.n_lanes = (uint32_t)n_lanes;
+  P.partials = (double *)c->partials.p;
+  P.stack = (uint32_t *)c->stack.p;
+  P.counters = (unsigned long long *)c->counters.p;
+
+  if (stats) HIPCHK(hipEventRecord(c->call_ev[0], st));
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), st));
+  const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
+  if (slot >= 0) HIPCHK(hipEventRecord(c->ev[slot][0], st));
+  int lrc = strict ? rtow::launch_trace_strict(P, kernel, (int)grid, kBlock, st)
+                   : rtow::launch_trace_fast(P, kernel, (int)grid, kBlock, st);
+  if (lrc != 0) return fail(RTOW_EHIP, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  if (slot >= 0) {
+    HIPCHK(hipEventRecord(c->ev[slot][1], st));
+    c->ev_count++;
+  }
+  rtow::ReduceParams R;
+  R.partials = P.partials;
+  R.out = (double *)d_rgb_sums;
+  R.npix3 = (uint32_t)(npix * 3);
+  R.nstreams = cfg->nstreams;
+  lrc = rtow::launch_reduce(R, st);
+  if (lrc != 0) return fail(RTOW_EHIP, "reduce kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+
+  if (stats) {
+    HIPCHK(hipEventRecord(c->call_ev[1], st));
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters.p, 4 * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->call_ev[0], c->call_ev[1]));
+    stats->total_ms = ms;
+    if (slot >= 0) {
+      HIPCHK(hipEventElapsedTime(&ms, c->ev[slot][0], c->ev[slot][1]));
+      stats->kernel_ms = ms;
+    }
+    stats->samples = npix * (unsigned long long)spt * (unsigned long long)cfg->nstreams;
+    stats->segments = c->h_counters[1];
+    if (kernel == RTOW_KERNEL_BRUTE) {
+      stats->prim_tests = stats->segments * (unsigned long long)c->n_prims;
+      stats->node_tests = 0;
+    } else {
+      stats->prim_tests = c->h_counters[2];
+      stats->node_tests = c->h_counters[3];
+    }
+  }
+  return RTOW_OK;
+}
+
+int rtow_profile_collect(rtow_ctx *c, double *kernel_ms_sum, int32_t *launches) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  double sum = 0.0;
+  for (int i = 0; i < c->ev_count; ++i) {
+    HIPCHK(hipEventSynchronize(c->ev[i][1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]));
+    sum += ms;
+  }
+  if (kernel_ms_sum) *kernel_ms_sum = sum;
+  if (launches) *launches = c->ev_count;
+  c->ev_count = 0;
+  return RTOW_OK;
+}
+
+int rtow_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, double *rgb_sums_host,
+                rtow_stats_t *stats) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  if (!rgb_sums_host) return fail(RTOW_EINVAL, "rgb_sums_host is NULL");
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  if ((rc = rtow_scene_upload(c, scene))) return rc;
+  const int rows = rtow_local_rows(cfg);
+  const size_t bytes = (size_t)rows * cfg->image_width * 3 * sizeof(double);
+  rtow_stats_t local;
+  if (bytes == 0) {
+    if (stats) {
+      std::memset(stats, 0, sizeof *stats);
+    }
+    return RTOW_OK;
+  }
+  void *d_out = nullptr;
+  HIPCHK(hipMalloc(&d_out, bytes));
+  rc = rtow_render_device(c, cfg, d_out, nullptr, stats ? stats : &local);
+  if (rc == RTOW_OK) {
+    hipError_t e = hipMemcpy(rgb_sums_host, d_out, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(RTOW_EHIP, "D2H copy failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_out);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// rtow_device.h — device-side data layout shared by the C-ABI shim and the kernels.
+//
+// Everything the trace kernel reads is laid out once at scene upload:
+//   * one packed record array per primitive class ("SoA across classes"); a record
+//     is a 32/64/96-byte aligned block of doubles, so the wave-uniform read of
+//     primitive i in the streaming kernel is a single scalar load (s_load_dwordx8/16)
+//     that lands in SGPRs and feeds the VALU as an operand — no VGPRs, no LDS
+//     traffic — and a per-lane read in the BVH kernel is 16-byte vector loads;
+//   * ray-independent per-primitive terms the reference recomputes in every hit
+//     test (r*r, c1-c0, e1, e2, e1×e2; src/common-model.cpp:73,106-108,
+//     src/oo-primitives.h:65) are computed once on the host with the same IEEE
+//     operations, so the results are bit-identical.
+#pragma once
+#include <stdint.h>
+
+namespace rtow {
+
+struct DevMaterial {       // 48 B
+  double att[3];           // attenuation: albedo (Lambertian, Metal) or (1,1,1) (Dielectric)
+  double fuzz;
+  double ir;
+  int32_t kind;
+  int32_t pad_;
+};
+
+struct DevCamera {         // src/common-model.h:104-112
+  double origin[3], u[3], v[3];
+  double horizontal[3], vertical[3], llc[3];
+  double lens_radius, t0, t1;
+};
+
+// class-major global primitive id: [0,n_sph) spheres, then moving, then triangles
+struct DevScene {
+  const double *sph;       // [n_sph][4]  cx cy cz r*r
+  const double *sph_r;     // [n_sph]     r (sign decides front_facing)
+  const double *mov;       // [n_mov][8]  c0xyz (c1-c0)xyz r*r r
+  const double *tri;       // [n_tri][12] a e1 e2 n=e1×e2
+  const int32_t *prim_mat; // [n_prims]   material index by class-major id
+  const DevMaterial *mats;
+  int32_t n_sph, n_mov, n_tri, n_mats;
+  // flattened BVH (kernel RTOW_KERNEL_BVH)
+  const double *bvh_box;   // [n_nodes][6] min xyz max xyz
+  const int32_t *bvh_link; // [n_nodes][4] left right first count  (count>0 → leaf)
+  const int32_t *bvh_prim; // leaf → class-major primitive ids
+  int32_t n_nodes, pad_;
+};
+
+struct TraceParams {
+  DevScene sc;
+  DevCamera cam;
+  int32_t W, H;            // full image
+  int32_t spt;             // samples per stream (= spp / nstreams)
+  int32_t nstreams;
+  int32_t max_child_rays;
+  int32_t rank, nranks, tile_rows;
+  int32_t local_rows;
+  uint32_t seed_lo, seed_hi;
+  uint32_t n_items;        // local_rows * W * nstreams
+  uint32_t n_lanes;        // grid * block (stride of the path stack)
+  double *partials;        // [nstreams][local_rows*W][3]
+  uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
+  unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests
+};
+
+struct ReduceParams {
+  const double *partials;
+  double *out;             // [local_rows*W][3]
+  uint32_t npix3;          // local_rows*W*3
+  int32_t nstreams;
+};
+
+// launchers, one pair per arithmetic mode (separate translation units compiled
+// with -ffp-contract=off / -ffp-contract=fast)
+int launch_trace_strict(const TraceParams &p, int kernel, int grid, int block, void *stream);
+int launch_trace_fast(const TraceParams &p, int kernel, int grid, int block, void *stream);
+int trace_occupancy_strict(int kernel, int block);
+int trace_occupancy_fast(int kernel, int block);
+int launch_reduce(const ReduceParams &p, void *stream);
+
+}  // namespace rtow

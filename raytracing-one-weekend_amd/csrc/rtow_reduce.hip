@@ -1,0 +1,25 @@
+// Stream reduce: global_image = sum over streams of the partial images, added in
+// stream order exactly like the reference joins its threads
+// (src/render.cpp:176-180: global = done + global, futures taken in launch order).
+#include <hip/hip_runtime.h>
+
+#include "rtow_device.h"
+
+namespace rtow {
+namespace {
+__global__ void __launch_bounds__(256) rtow_reduce_streams(const ReduceParams p) {
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= p.npix3) return;
+  double g = 0.0;
+  for (int k = 0; k < p.nstreams; ++k) g = p.partials[(size_t)k * p.npix3 + idx] + g;
+  p.out[idx] = g;
+}
+}  // namespace
+
+int launch_reduce(const ReduceParams &p, void *stream) {
+  const unsigned grid = (p.npix3 + 255u) / 256u;
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL(rtow_reduce_streams, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return (int)hipGetLastError();
+}
+}  // namespace rtow

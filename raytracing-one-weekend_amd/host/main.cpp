@@ -1,0 +1,107 @@
+// main.cpp — `rtweekend` command line, flag-compatible with the reference's
+// src/main.cpp:138-170 (CLI11 is not in this image: a small parser of the same
+// short/long flags), plus the device knobs the reference has no notion of.
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+#include "render.h"
+
+namespace rt = rtweekend;
+
+static void usage(const char *argv0) {
+  std::cout << "Raytracing one weekend/week/restoflife (MI355X HIP path)\n"
+               "Usage: "
+            << argv0
+            << " [OPTIONS]\n\n"
+               "  -h,--help                   Print this help message and exit\n"
+               "  -t,--threads INT            Number of sample streams (the reference's threads)\n"
+               "  -w,--image-width INT        Image width\n"
+               "  -s,--samples-per-pixel INT  Samples per pixel\n"
+               "  -c,--max-child-rays INT     Max child rays\n"
+               "  -a,--aspect-ratio FLOAT     Aspect ratio\n"
+               "  -n,--balls_sqrt INT         Number of balls sqrt\n"
+               "  -m,--moving-spheres         Moving spheres\n"
+               "  -q,--quick                  Quickie\n"
+               "  --dry-run                   Dry run\n"
+               "  -l,--load TEXT              Model to load\n"
+               "  --device INT                HIP device index (default 0)\n"
+               "  --seed UINT                 render seed of the counter-based RNG (default 1)\n"
+               "  --precision strict|fast     f64 without / with FMA contraction (default fast)\n"
+               "  --kernel auto|brute|bvh     closest-hit strategy (default auto)\n";
+}
+
+int main(int argc, char *argv[]) {
+  rt::Config cfg{};
+  bool dry_run = false;
+  rt::DeviceOptions &opt = rt::device_options();
+
+  auto is = [](const char *a, const char *s, const char *l) {
+    return std::strcmp(a, s) == 0 || std::strcmp(a, l) == 0;
+  };
+  try {
+    for (int i = 1; i < argc; ++i) {
+      const char *a = argv[i];
+      auto value = [&]() -> const char * {
+        if (i + 1 >= argc) throw std::runtime_error(std::string(a) + ": 1 required TEXT missing");
+        return argv[++i];
+      };
+      if (is(a, "-h", "--help")) {
+        usage(argv[0]);
+        return 0;
+      } else if (is(a, "-t", "--threads")) {
+        cfg.nthreads = std::stoi(value());
+      } else if (is(a, "-w", "--image-width")) {
+        cfg.image_width = std::stoi(value());
+      } else if (is(a, "-s", "--samples-per-pixel")) {
+        cfg.samples_per_pixel = std::stoi(value());
+      } else if (is(a, "-c", "--max-child-rays")) {
+        cfg.max_child_rays = std::stoi(value());
+      } else if (is(a, "-a", "--aspect-ratio")) {
+        cfg.aspect_ratio = std::stod(value());
+      } else if (is(a, "-n", "--balls_sqrt")) {
+        cfg.number_of_balls_sqrt = std::stoi(value());
+      } else if (is(a, "-m", "--moving-spheres")) {
+        cfg.moving_spheres = true;
+      } else if (is(a, "-q", "--quick")) {
+        // parsed and ignored, like the reference (src/main.cpp:142,157)
+      } else if (std::strcmp(a, "--dry-run") == 0) {
+        dry_run = true;
+      } else if (is(a, "-l", "--load")) {
+        cfg.model = std::string(value());
+      } else if (std::strcmp(a, "--device") == 0) {
+        opt.device = std::stoi(value());
+      } else if (std::strcmp(a, "--seed") == 0) {
+        opt.seed = std::stoull(value());
+      } else if (std::strcmp(a, "--precision") == 0) {
+        const std::string v = value();
+        if (v == "strict") opt.precision = 0;
+        else if (v == "fast") opt.precision = 1;
+        else throw std::runtime_error("--precision: strict|fast");
+      } else if (std::strcmp(a, "--kernel") == 0) {
+        const std::string v = value();
+        if (v == "auto") opt.kernel = 0;
+        else if (v == "brute") opt.kernel = 1;
+        else if (v == "bvh") opt.kernel = 2;
+        else throw std::runtime_error("--kernel: auto|brute|bvh");
+      } else {
+        throw std::runtime_error(std::string("The following argument was not expected: ") + a);
+      }
+    }
+  } catch (const std::exception &e) {
+    std::cerr << e.what() << "\nRun with --help for more information.\n";
+    return 109;  // CLI11's exit code for parse errors of this kind
+  }
+
+  if (dry_run) {
+    std::cout << cfg;
+    return 0;
+  }
+  if (cfg.model) {
+    rt::render(rt::detail::foo(cfg), cfg);
+  } else {
+    rt::render(rt::detail::lots_of_balls(cfg), cfg);
+  }
+}

@@ -1,0 +1,252 @@
+// render.cpp — host side of the boundary: Camera set-up, Scene flattening, the
+// call into the HIP path through the C-ABI, and the reference's PPM writer.
+#include "render.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/rtow.h"
+
+namespace rtweekend::detail {
+
+// src/common-model.cpp:136-154 — same expressions, same order.
+Camera::Camera(point lookfrom, point lookat, vec3 vup, double fov, double aspect_ratio,
+               double aperture, std::optional<double> focus_dist, time_t t0, time_t t1)
+    : origin_{lookfrom},
+      w_{normalize(lookfrom - lookat)},
+      u_{normalize(cross(vup, w_))},
+      v_{normalize(cross(w_, u_))},
+      lens_radius_{aperture / 2},
+      t0_{t0},
+      t1_{t1} {
+  const double pi = 3.141592653589793238462643383279502884;
+  auto viewport_height = 2.0 * std::tan(fov * pi / 180 / 2);
+  auto viewport_width = aspect_ratio * viewport_height;
+  auto fd = focus_dist ? focus_dist.value() : length(lookfrom - lookat);
+  horizontal_ = fd * viewport_width * u_;
+  vertical_ = fd * viewport_height * v_;
+  lower_left_corner_ = origin_ - horizontal_ / 2.0 - vertical_ / 2.0 - fd * w_;
+}
+
+DeviceOptions &device_options() {
+  static DeviceOptions o;
+  return o;
+}
+
+// ------------------------------------------------------------------ flatten ---
+struct FlatScene {
+  rtow_scene_t s{};
+  std::vector<double> sg, mg, tg;
+  std::vector<int32_t> sm, mm, tm, pk, pi;
+  std::vector<rtow_material_t> mats;
+  void bind() {
+    s.n_spheres = (int32_t)sm.size();
+    s.sphere_geom = sg.data();
+    s.sphere_mat = sm.data();
+    s.n_moving = (int32_t)mm.size();
+    s.moving_geom = mg.data();
+    s.moving_mat = mm.data();
+    s.n_triangles = (int32_t)tm.size();
+    s.triangle_geom = tg.data();
+    s.triangle_mat = tm.data();
+    s.n_materials = (int32_t)mats.size();
+    s.materials = mats.data();
+    s.n_prims = (int32_t)pk.size();
+    s.prim_kind = pk.data();
+    s.prim_index = pi.data();
+  }
+};
+
+static void put3(double *d, const vec3 &v) {
+  d[0] = v.x;
+  d[1] = v.y;
+  d[2] = v.z;
+}
+
+FlatScene *flatten(const Scene &world) {
+  auto *f = new FlatScene();
+  const Camera &c = world.camera();
+  put3(f->s.camera.origin, c.origin());
+  put3(f->s.camera.u, c.u());
+  put3(f->s.camera.v, c.v());
+  put3(f->s.camera.w, c.w());
+  put3(f->s.camera.horizontal, c.horizontal());
+  put3(f->s.camera.vertical, c.vertical());
+  put3(f->s.camera.lower_left_corner, c.lower_left_corner());
+  f->s.camera.lens_radius = c.lens_radius();
+  f->s.camera.t0 = c.t0();
+  f->s.camera.t1 = c.t1();
+
+  std::unordered_map<const Material *, int32_t> mat_index;
+  for (auto it = world.boutique().cbegin(); it != world.boutique().cend(); ++it) {
+    const Material *m = it->get();
+    rtow_material_t r;
+    std::memset(&r, 0, sizeof r);
+    r.kind = static_cast<int32_t>(m->kind());
+    switch (m->kind()) {
+      case Material::Kind::lambertian:
+        put3(r.albedo, static_cast<const Lambertian *>(m)->albedo);
+        break;
+      case Material::Kind::metal:
+        put3(r.albedo, static_cast<const Metal *>(m)->albedo);
+        r.fuzz = static_cast<const Metal *>(m)->fuzz;
+        break;
+      case Material::Kind::dielectric:
+        r.ir = static_cast<const Dielectric *>(m)->ir;
+        r.fuzz = static_cast<const Dielectric *>(m)->fuzz;
+        break;
+    }
+    mat_index[m] = (int32_t)f->mats.size();
+    f->mats.push_back(r);
+  }
+  for (auto it = world.primitives().cbegin(); it != world.primitives().cend(); ++it) {
+    const Primitive *p = it->get();
+    auto found = mat_index.find(&p->material());
+    if (found == mat_index.end()) {
+      delete f;
+      throw std::runtime_error("primitive refers to a material that is not in the scene's boutique");
+    }
+    const int32_t mi = found->second;
+    f->pk.push_back(static_cast<int32_t>(p->kind()));
+    switch (p->kind()) {
+      case Primitive::Kind::sphere: {
+        auto *s = static_cast<const Sphere *>(p);
+        f->pi.push_back((int32_t)f->sm.size());
+        f->sg.insert(f->sg.end(), {s->center().x, s->center().y, s->center().z, s->radius()});
+        f->sm.push_back(mi);
+        break;
+      }
+      case Primitive::Kind::moving_sphere: {
+        auto *s = static_cast<const MovingSphere *>(p);
+        f->pi.push_back((int32_t)f->mm.size());
+        f->mg.insert(f->mg.end(), {s->center().x, s->center().y, s->center().z, s->center1().x,
+                                   s->center1().y, s->center1().z, s->radius(), 0.0});
+        f->mm.push_back(mi);
+        break;
+      }
+      case Primitive::Kind::triangle: {
+        auto *t = static_cast<const Triangle *>(p);
+        f->pi.push_back((int32_t)f->tm.size());
+        f->tg.insert(f->tg.end(), {t->a().x, t->a().y, t->a().z, t->b().x, t->b().y, t->b().z,
+                                   t->c().x, t->c().y, t->c().z});
+        f->tm.push_back(mi);
+        break;
+      }
+    }
+  }
+  f->bind();
+  return f;
+}
+
+const rtow_scene_t *flat_view(const FlatScene *f) { return &f->s; }
+void flat_free(FlatScene *f) { delete f; }
+
+template <class T>
+static T *dup_array(const std::vector<T> &v) {
+  T *p = static_cast<T *>(std::malloc(sizeof(T) * (v.empty() ? 1 : v.size())));
+  if (!v.empty()) std::memcpy(p, v.data(), sizeof(T) * v.size());
+  return p;
+}
+
+rtow_scene_t *flat_release(FlatScene *f) {
+  auto *s = static_cast<rtow_scene_t *>(std::malloc(sizeof(rtow_scene_t)));
+  *s = f->s;
+  s->sphere_geom = dup_array(f->sg);
+  s->sphere_mat = dup_array(f->sm);
+  s->moving_geom = dup_array(f->mg);
+  s->moving_mat = dup_array(f->mm);
+  s->triangle_geom = dup_array(f->tg);
+  s->triangle_mat = dup_array(f->tm);
+  s->materials = dup_array(f->mats);
+  s->prim_kind = dup_array(f->pk);
+  s->prim_index = dup_array(f->pi);
+  delete f;
+  return s;
+}
+
+// ------------------------------------------------------------------- render ---
+// src/render.cpp:11-20
+static void write_color(std::string &out, double r, double g, double b, int samples_per_pixel) {
+  const double d = static_cast<double>(samples_per_pixel);
+  const double c[3] = {std::sqrt(r / d), std::sqrt(g / d), std::sqrt(b / d)};
+  char buf[48];
+  int n = std::snprintf(buf, sizeof buf, "%d %d %d\n",
+                        static_cast<int>(256 * std::clamp(c[0], 0.0, 0.999)),
+                        static_cast<int>(256 * std::clamp(c[1], 0.0, 0.999)),
+                        static_cast<int>(256 * std::clamp(c[2], 0.0, 0.999)));
+  out.append(buf, (size_t)n);
+}
+
+std::string ppm_text(const double *rgb_sums, int width, int height, int spp_effective) {
+  std::string s;
+  s.reserve((size_t)width * height * 12 + 32);
+  s += "P3\n" + std::to_string(width) + ' ' + std::to_string(height) + "\n255\n";  // :182
+  for (size_t p = 0; p < (size_t)width * height; ++p)
+    write_color(s, rgb_sums[p * 3], rgb_sums[p * 3 + 1], rgb_sums[p * 3 + 2], spp_effective);
+  return s;
+}
+
+void render(const Scene &world, const Config &cfg) {
+  int image_height = static_cast<int>(cfg.image_width / cfg.aspect_ratio);  // src/render.cpp:137
+  namespace khr = std::chrono;
+  const DeviceOptions &opt = device_options();
+  std::cerr << "Started rendering with " << cfg.nthreads << " sample streams on HIP device "
+            << opt.device << "\n";
+  khr::time_point start{khr::high_resolution_clock::now()};
+
+  FlatScene *flat = flatten(world);
+  rtow_config_t rc;
+  std::memset(&rc, 0, sizeof rc);
+  rc.image_width = cfg.image_width;
+  rc.image_height = image_height;
+  rc.samples_per_pixel = cfg.samples_per_pixel;
+  rc.nstreams = cfg.nthreads;
+  rc.max_child_rays = cfg.max_child_rays;
+  rc.precision = opt.precision;
+  rc.kernel = opt.kernel;
+  rc.rank = 0;
+  rc.nranks = 1;
+  rc.tile_rows = 8;
+  rc.seed = opt.seed;
+
+  std::vector<double> image((size_t)cfg.image_width * (image_height > 0 ? image_height : 0) * 3);
+  rtow_ctx *ctx = nullptr;
+  rtow_stats_t st;
+  int err = rtow_ctx_create(opt.device, &ctx);
+  if (err == RTOW_OK) err = rtow_render(ctx, flat_view(flat), &rc, image.data(), &st);
+  std::string msg = err == RTOW_OK ? "" : rtow_last_error();
+  rtow_ctx_destroy(ctx);
+  flat_free(flat);
+  if (err != RTOW_OK) throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + msg);
+
+  const int spp_eff = cfg.samples_per_pixel / cfg.nthreads * cfg.nthreads;  // src/render.cpp:185
+  std::cout << ppm_text(image.data(), cfg.image_width, image_height, spp_eff);
+
+  auto took = khr::high_resolution_clock::now() - start;
+  std::cerr << "Traced " << st.samples << " samples, " << st.segments << " ray segments; kernel "
+            << st.kernel_ms << " ms ("
+            << (st.kernel_ms > 0 ? st.samples / st.kernel_ms / 1e3 : 0.0) << " Msamples/s)\n";
+  std::cerr << "\nDone in " << khr::duration_cast<khr::milliseconds>(took).count() << "ms\n";
+}
+
+// src/render.cpp:193-203
+std::ostream &operator<<(std::ostream &o, const Config &c) {
+  return o << "Config {\n"
+           << "aspect_ratio: " << c.aspect_ratio << "\n"
+           << "number_of_balls_sqrt: " << c.number_of_balls_sqrt << "\n"
+           << "moving_spheres: " << c.moving_spheres << "\n"
+           << "image_width: " << c.image_width << "\n"
+           << "samples_per_pixel: " << c.samples_per_pixel << "\n"
+           << "max_child_rays: " << c.max_child_rays << "\n"
+           << "nthreads: " << c.nthreads << "\n"
+           << "}\n";
+}
+
+}  // namespace rtweekend::detail

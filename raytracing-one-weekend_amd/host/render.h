@@ -1,0 +1,76 @@
+// render.h — Config, Scene and render(): the boundary the device path sits behind.
+// Same names, fields and defaults as the reference's src/render.h:11-35.
+#pragma once
+#include <cstdint>
+#include <iosfwd>
+#include <optional>
+#include <string>
+
+#include "primitives.h"
+
+struct rtow_scene_t;
+
+namespace rtweekend::detail {
+
+struct Config {
+  int number_of_balls_sqrt = 11;
+  double aspect_ratio = 3.0 / 2.0;
+  int image_width = 200;
+  int samples_per_pixel = 20;
+  bool moving_spheres = true;
+  int max_child_rays = 20;
+  int nthreads = 4;  // on the device: number of sample streams per pixel (same spp rounding)
+  std::optional<std::string> model = {};
+};
+
+// Knobs of the device path that have no counterpart in the reference's Config.
+struct DeviceOptions {
+  int device = 0;
+  uint64_t seed = 1;
+  int precision = 1;  // RTOW_F64_FAST; 0 = RTOW_F64_STRICT
+  int kernel = 0;     // RTOW_KERNEL_AUTO
+};
+DeviceOptions &device_options();
+
+class Scene {
+  mutable PrimitiveStore_t primitives_;
+  MaterialStore_t boutique_;
+  Camera cam_;
+
+ public:
+  template <typename T>
+  explicit Scene(T &&camera) : cam_{std::forward<T>(camera)} {}
+  auto &camera() const { return cam_; }
+  auto &primitives() { return primitives_; }
+  const auto &primitives() const { return primitives_; }
+  auto &boutique() { return boutique_; }
+  const auto &boutique() const { return boutique_; }
+};
+
+// Flattened copy of a Scene (owns the arrays an rtow_scene_t points into).
+struct FlatScene;
+FlatScene *flatten(const Scene &world);
+const rtow_scene_t *flat_view(const FlatScene *f);
+rtow_scene_t *flat_release(FlatScene *f);  // heap rtow_scene_t owning malloc'ed arrays
+void flat_free(FlatScene *f);
+
+// Renders on the GPU through the C-ABI and writes the P3 PPM to std::cout,
+// diagnostics to std::cerr (src/render.cpp:135-191).  Throws std::runtime_error
+// if the device path fails — there is no CPU fallback.
+void render(const Scene &world, const Config &cfg);
+
+std::ostream &operator<<(std::ostream &o, const Config &c);
+
+// The two scene scripts of the reference's main.cpp.
+Scene lots_of_balls(const Config &cfg);  // src/main.cpp:23-83
+Scene foo(const Config &cfg);            // src/main.cpp:85-136
+
+}  // namespace rtweekend::detail
+
+namespace rtweekend {
+using detail::Config;
+using detail::DeviceOptions;
+using detail::device_options;
+using detail::render;
+using detail::Scene;
+}  // namespace rtweekend

@@ -1,0 +1,177 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
+
+Bars:
+  strict build  — bit-identical f64 radiance sums to oracle/ with the same Philox seed;
+  fast build    — FMA contraction flips rare hit/miss decisions, so parity is by
+                  tolerance: mean |Δ| per channel ≤ 2e-3 (linear radiance, per sample
+                  average) at the small test sizes and ≤ 0.1 % of 8-bit channels off by
+                  more than one level at ≥ 64 spp.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+import rtow
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (scene kind, args, width, aspect, spp, nstreams, depth, seed) — same as make_fixtures.py
+    "c1_3spheres": ("cover", (0, 16 / 9, True), 64, 16 / 9, 8, 2, 10, 7),
+    "cover_static": ("cover", (11, 1.5, False), 60, 1.5, 4, 2, 50, 1),
+    "cover_moving": ("cover", (11, 1.5, True), 60, 1.5, 4, 1, 50, 3),
+    "suzanne": ("obj", (16 / 9,), 64, 16 / 9, 4, 2, 20, 5),
+}
+
+
+def make_scene(kind, args):
+    if kind == "cover":
+        return rtow.HostScene.cover(*args)
+    return rtow.HostScene.obj(GOLDEN / "suzanne.obj", *args)
+
+
+def to8(img, spp):
+    return (256 * np.clip(np.sqrt(img / spp), 0.0, 0.999)).astype(np.int32)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_strict_is_bit_identical_to_oracle_and_golden(ctx, name):
+    kind, args, w, aspect, spp, ns, depth, seed = CASES[name]
+    scene = make_scene(kind, args)
+    cfg = rtow.make_config(w, rtow.image_height(w, aspect), spp, ns, depth, seed=seed,
+                           precision=rtow.F64_STRICT, kernel=rtow.KERNEL_BRUTE)
+    img, st = ctx.render(scene, cfg)
+    ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+    assert img.shape == ref.shape
+    assert np.array_equal(img, ref), f"{int((img != ref).sum())} of {img.size} values differ"
+    assert st.segments == ost.segments and st.samples == ost.samples
+    gold = np.load(GOLDEN / "oracle_philox.npz")
+    assert np.array_equal(img, gold[name + "_img"])
+    assert st.segments == int(gold[name + "_segments"][0])
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fast_build_within_tolerance(ctx, name):
+    kind, args, w, aspect, spp, ns, depth, seed = CASES[name]
+    scene = make_scene(kind, args)
+    cfg = rtow.make_config(w, rtow.image_height(w, aspect), spp, ns, depth, seed=seed,
+                           precision=rtow.F64_FAST, kernel=rtow.KERNEL_BRUTE)
+    img, st = ctx.render(scene, cfg)
+    ref = np.load(GOLDEN / "oracle_philox.npz")[name + "_img"]
+    assert np.isfinite(img).all()
+    assert np.abs(img - ref).mean() / spp <= 2e-3
+    # almost every pixel is still identical to rounding
+    close = np.isclose(img, ref, rtol=1e-9, atol=1e-12).all(axis=-1).mean()
+    assert close > 0.97, close
+
+
+def test_fast_build_8bit_agreement_at_64spp(ctx):
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    cfg = rtow.make_config(96, 64, 64, 4, 50, seed=21, precision=rtow.F64_FAST)
+    img, _ = ctx.render(scene, cfg)
+    ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+    off = np.abs(to8(img, 64) - to8(ref, 64)) > 1
+    assert off.mean() <= 1e-3, off.mean()
+    assert np.abs(img - ref).mean() / 64 <= 1e-4
+
+
+def test_image_does_not_depend_on_the_partition(ctx):
+    scene = rtow.HostScene.cover(11, 1.5, True)
+    W, H = 50, 37
+    base = rtow.make_config(W, H, 6, 3, 20, seed=4, precision=rtow.F64_STRICT)
+    whole, _ = ctx.render(scene, base)
+    for nranks, tile in ((2, 4), (3, 5), (8, 1), (8, 8)):
+        full = np.full_like(whole, np.nan)
+        for r in range(nranks):
+            cfg = rtow.make_config(W, H, 6, 3, 20, seed=4, precision=rtow.F64_STRICT, rank=r,
+                                   nranks=nranks, tile_rows=tile)
+            part, st = ctx.render(scene, cfg)
+            rows = rtow.local_rows(cfg)
+            assert part.shape[0] == len(rows) == st.local_rows
+            if rows:
+                full[rows] = part
+        assert np.array_equal(full, whole), (nranks, tile)
+
+
+def test_repeatable_and_independent_of_stream_count_in_expectation(ctx):
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    cfg = rtow.make_config(48, 32, 12, 3, 50, seed=8, precision=rtow.F64_FAST)
+    a, _ = ctx.render(scene, cfg)
+    b, _ = ctx.render(scene, cfg)
+    assert np.array_equal(a, b)  # dynamic work distribution must not leak into the image
+    # same samples, different summation tree: equal to rounding only
+    cfg1 = rtow.make_config(48, 32, 12, 1, 50, seed=8, precision=rtow.F64_FAST)
+    c, _ = ctx.render(scene, cfg1)
+    assert np.allclose(a, c, rtol=1e-12, atol=1e-12) and not np.array_equal(a, c)
+    # another seed: a different image
+    cfg2 = rtow.make_config(48, 32, 12, 3, 50, seed=9, precision=rtow.F64_FAST)
+    d, _ = ctx.render(scene, cfg2)
+    assert not np.array_equal(a, d)
+
+
+def test_depth_zero_and_rounded_down_spp(ctx):
+    scene = rtow.HostScene.cover(0, 1.5, False)
+    # max_child_rays = 0: every hit is black, every miss is sky (src/render.cpp:113-115)
+    cfg = rtow.make_config(32, 20, 4, 2, 0, seed=3, precision=rtow.F64_STRICT)
+    img, st = ctx.render(scene, cfg)
+    ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX)
+    assert np.array_equal(img, ref) and st.segments == st.samples == ost.samples
+    # spp 7 over 3 streams -> 6 effective samples (src/render.cpp:174,185)
+    cfg = rtow.make_config(32, 20, 7, 3, 5, seed=3, precision=rtow.F64_STRICT)
+    img, st = ctx.render(scene, cfg)
+    ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX)
+    assert st.samples == 32 * 20 * 6 and np.array_equal(img, ref)
+    # fewer samples than streams -> zero samples, black image, no hang
+    cfg = rtow.make_config(32, 20, 2, 3, 5, seed=3, precision=rtow.F64_STRICT)
+    img, st = ctx.render(scene, cfg)
+    assert st.samples == 0 and not img.any()
+
+
+def test_error_paths(ctx):
+    L = rtow.lib()
+    fresh = rtow.Context(0)
+    cfg = rtow.make_config(8, 8, 1)
+    assert L.rtow_render_device(fresh._h, C.byref(cfg), C.c_void_p(8), None, None) == rtow.RTOW_ENOSCENE
+    scene = rtow.HostScene.cover(0, 1.5, False)
+    empty = rtow.Scene()
+    empty.camera = scene.c.camera
+    assert L.rtow_scene_upload(fresh._h, C.byref(empty)) == rtow.RTOW_EEMPTY  # ref.: UB
+    s = scene.c
+    bad = rtow.Scene.from_buffer_copy(s)
+    bad_mats = (C.c_int32 * s.n_spheres)(*([s.n_materials] * s.n_spheres))
+    bad.sphere_mat = C.cast(bad_mats, C.POINTER(C.c_int32))
+    assert L.rtow_scene_upload(fresh._h, C.byref(bad)) == rtow.RTOW_EINVAL
+    assert b"material index" in L.rtow_last_error()
+    fresh.upload(scene)
+    assert L.rtow_render_device(fresh._h, C.byref(cfg), None, None, None) == rtow.RTOW_EINVAL
+    fresh.close()
+
+
+def test_full_size_cover_properties(ctx):
+    """BASELINE config C2 (1200x800, 100 spp, 50 bounces) through size-independent
+    properties: sample/segment accounting, sky pixels, statistics vs a low-spp oracle
+    render of the same scene, and 8-way strip reassembly at full size."""
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    W, H, spp, ns = 1200, 800, 100, 10
+    cfg = rtow.make_config(W, H, spp, ns, 50, seed=1, precision=rtow.F64_FAST)
+    img, st = ctx.render(scene, cfg)
+    assert st.samples == W * H * spp
+    assert abs(st.segments / st.samples - 2.43) < 0.02
+    assert np.isfinite(img).all() and (img >= 0).all()
+    # the top-left pixel only sees sky: every sample is (1-t)*white + t*(0.5,0.7,1.0)
+    px = img[0, 0] / spp
+    assert 0.5 <= px[0] <= 1.0 and px[0] <= px[1] <= px[2] == 1.0
+    # oracle at reduced resolution (same camera): channel means agree within MC noise
+    small = rtow.make_config(150, 100, 16, 1, 50, seed=2)
+    ref, _ = orc.render(scene, small, orc.RNG_PHILOX, nthreads=8)
+    m_gpu, m_ref = img.mean(axis=(0, 1)) / spp, ref.mean(axis=(0, 1)) / 16
+    assert np.all(np.abs(m_gpu - m_ref) < 0.01), (m_gpu, m_ref)
+    # strips of 8 rows over 8 ranks: rank 3's rows equal the same rows of the whole image
+    part_cfg = rtow.make_config(W, H, spp, ns, 50, seed=1, precision=rtow.F64_FAST, rank=3,
+                                nranks=8, tile_rows=8)
+    part, pst = ctx.render(scene, part_cfg)
+    rows = rtow.local_rows(part_cfg)
+    assert len(rows) == 96 and np.array_equal(part, img[rows])

@@ -1,0 +1,142 @@
+"""Unit checks of the oracle's building blocks: RNG known answers, hit tests on
+hand-computable cases, and properties of the Philox render mode."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+import rtow
+
+_pd = C.POINTER(C.c_double)
+
+
+def _d3(*v):
+    return (C.c_double * 3)(*v)
+
+
+def test_philox4x32_10_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    L = orc.lib()
+    for ctr, key, want in kat:
+        out = (C.c_uint32 * 4)()
+        L.orc_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        assert tuple(out) == want
+
+
+def test_mt19937_stream_and_double_mapping():
+    L = orc.lib()
+    L.orc_mt_reset()
+    # std::mt19937 default seed: first two outputs are 3499211612, 581869302
+    want = (3499211612 + 581869302 * 2.0**32) / 2.0**64
+    assert L.orc_mt_random_double(0.0, 1.0) == want
+    L.orc_mt_reset()
+    assert L.orc_mt_random_double(-1.0, 1.0) == want * 2.0 + -1.0
+
+
+def test_philox_double_is_a_pure_function_of_its_key():
+    L = orc.lib()
+    a = L.orc_philox_double(42, 1000, 7, 3)
+    assert a == L.orc_philox_double(42, 1000, 7, 3)
+    assert 0.0 <= a < 1.0
+    vals = {L.orc_philox_double(42, p, s, d) for p in range(4) for s in range(4) for d in range(6)}
+    assert len(vals) == 96
+    assert L.orc_philox_double(43, 1000, 7, 3) != a
+
+
+def test_sphere_hit_cases():
+    L = orc.lib()
+    t, p, n = C.c_double(), _d3(0, 0, 0), _d3(0, 0, 0)
+    front = C.c_int()
+    # ray along -z from (0,0,5) at unit sphere: roots 4 and 6
+    assert L.orc_sphere_hit(_d3(0, 0, 0), 1.0, _d3(0, 0, 5), _d3(0, 0, -1), 0.001, np.inf,
+                            C.byref(t), p, n, C.byref(front)) == 1
+    assert t.value == 4.0 and tuple(p) == (0, 0, 1) and tuple(n) == (0, 0, 1) and front.value == 1
+    # from inside: first root negative -> second root, back face, flipped normal
+    assert L.orc_sphere_hit(_d3(0, 0, 0), 1.0, _d3(0, 0, 0), _d3(0, 0, -1), 0.001, np.inf,
+                            C.byref(t), p, n, C.byref(front)) == 1
+    assert t.value == 1.0 and front.value == 0 and tuple(n) == (0, 0, 1)
+    # negative radius flips front_facing (src/common-model.cpp:88)
+    assert L.orc_sphere_hit(_d3(0, 0, 0), -1.0, _d3(0, 0, 5), _d3(0, 0, -1), 0.001, np.inf,
+                            C.byref(t), p, n, C.byref(front)) == 1
+    assert front.value == 0
+    # tmax is inclusive (root > tmax rejects), tmin is inclusive too
+    assert L.orc_sphere_hit(_d3(0, 0, 0), 1.0, _d3(0, 0, 5), _d3(0, 0, -1), 0.001, 4.0,
+                            C.byref(t), p, n, C.byref(front)) == 1
+    assert L.orc_sphere_hit(_d3(0, 0, 0), 1.0, _d3(0, 0, 5), _d3(0, 0, -1), 0.001, 3.999,
+                            C.byref(t), p, n, C.byref(front)) == 0
+    # un-normalised direction scales t
+    assert L.orc_sphere_hit(_d3(0, 0, 0), 1.0, _d3(0, 0, 5), _d3(0, 0, -2), 0.001, np.inf,
+                            C.byref(t), p, n, C.byref(front)) == 1
+    assert t.value == 2.0
+    # miss
+    assert L.orc_sphere_hit(_d3(0, 0, 0), 1.0, _d3(0, 2, 5), _d3(0, 0, -1), 0.001, np.inf,
+                            C.byref(t), p, n, C.byref(front)) == 0
+
+
+def test_triangle_hit_cases():
+    L = orc.lib()
+    t, p, n = C.c_double(), _d3(0, 0, 0), _d3(0, 0, 0)
+    a, b, c = _d3(0, 0, 0), _d3(1, 0, 0), _d3(0, 1, 0)  # normal +z, un-normalised (0,0,1)
+    assert L.orc_triangle_hit(a, b, c, _d3(0.25, 0.25, 1), _d3(0, 0, -1), 0.001, np.inf,
+                              C.byref(t), p, n) == 1
+    assert t.value == 1.0 and tuple(n) == (0, 0, 1) and tuple(p) == (0.25, 0.25, 0)
+    # back face is culled (det >= 1e-6)
+    assert L.orc_triangle_hit(a, b, c, _d3(0.25, 0.25, -1), _d3(0, 0, 1), 0.001, np.inf,
+                              C.byref(t), p, n) == 0
+    # outside the edge u+v<=1
+    assert L.orc_triangle_hit(a, b, c, _d3(0.75, 0.75, 1), _d3(0, 0, -1), 0.001, np.inf,
+                              C.byref(t), p, n) == 0
+    # the normal is the raw cross product: scale the triangle by 2 -> |n| = 4
+    assert L.orc_triangle_hit(a, _d3(2, 0, 0), _d3(0, 2, 0), _d3(0.5, 0.5, 1), _d3(0, 0, -1),
+                              0.001, np.inf, C.byref(t), p, n) == 1
+    assert tuple(n) == (0, 0, 4)
+
+
+def test_aabb_hit_quirks():
+    L = orc.lib()
+    lo, hi = _d3(-1, -1, -1), _d3(1, 1, 1)
+    assert L.orc_aabb_hit(lo, hi, _d3(0, 0, 5), _d3(0, 0, -1), 0.001, np.inf) == 1
+    assert L.orc_aabb_hit(lo, hi, _d3(0, 2, 5), _d3(0, 0, -1), 0.001, np.inf) == 0
+    # zero-thickness box is never hit (t_max <= t_min), src/common-model.h:80
+    assert L.orc_aabb_hit(_d3(-1, -1, 0), _d3(1, 1, 0), _d3(0, 0, 5), _d3(0, 0, -1), 0.001,
+                          np.inf) == 0
+
+
+def test_philox_render_is_thread_and_partition_invariant():
+    scene = orc.OrcScene.cover(3, 1.5, True)
+    cfg = rtow.make_config(30, 20, 6, nstreams=3, max_child_rays=8, seed=5)
+    a, sa = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=1)
+    b, sb = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=4)
+    assert np.array_equal(a, b) and sa.segments == sb.segments
+    # two "ranks" with 3-row strips reassemble to the same image
+    full = np.zeros_like(a)
+    for r in range(2):
+        cr = rtow.make_config(30, 20, 6, 3, 8, seed=5, rank=r, nranks=2, tile_rows=3)
+        part, _ = orc.render(scene, cr, orc.RNG_PHILOX)
+        rows = [i for i in range(20) if (i // 3) % 2 == r]
+        full[rows] = part
+    assert np.array_equal(full, a)
+
+
+def test_effective_spp_rounds_down_like_the_reference():
+    scene = orc.OrcScene.cover(0, 1.5, False)
+    cfg = rtow.make_config(8, 5, 7, nstreams=3, max_child_rays=4, seed=2)  # 7/3*3 = 6 samples
+    _, st = orc.render(scene, cfg, orc.RNG_PHILOX)
+    assert st.samples == 8 * 5 * 6
+    assert rtow.spp_effective(cfg) == 6
+
+
+def test_philox_and_mt_images_agree_statistically():
+    """Different streams, same estimator: image means agree within Monte-Carlo noise."""
+    scene = orc.OrcScene.cover(11, 1.5, False)
+    cfg = rtow.make_config(60, 40, 16, 1, 50, seed=9)
+    a, _ = orc.render(scene, cfg, orc.RNG_MT19937)
+    b, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=4)
+    ma, mb = a.mean(axis=(0, 1)) / 16, b.mean(axis=(0, 1)) / 16
+    assert np.all(np.abs(ma - mb) < 0.01), (ma, mb)
