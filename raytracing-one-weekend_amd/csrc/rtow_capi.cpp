@@ -346,6 +346,12 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
     stats->kernel_used = kernel;
   }
   if (npix == 0) return RTOW_OK;
+  if (spt == 0) {
+    // fewer samples than streams: zero effective samples (src/render.cpp:174), black sums
+    HIPCHK(hipMemsetAsync(d_rgb_sums, 0, (size_t)npix * 3 * sizeof(double), st));
+    if (stats) HIPCHK(hipStreamSynchronize(st));
+    return RTOW_OK;
+  }
 
   // grid: as many 256-lane blocks as stay resident, but no more than there are items
   int &occ = c->occ[strict ? 0 : 1];

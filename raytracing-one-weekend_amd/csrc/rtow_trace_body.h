@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const 
   for (;;) {
     // ---- item bookkeeping ---------------------------------------------------
     bool need_item = false;
-    if (!done && need_sample && s_left == 0) {
+    if (!done && need_sample && s_left <= 0) {
       if (item != 0xffffffffu) {
         double *dst = P.partials + (size_t)item * 3;
         dst[0] = acc.x;
@@ -308,7 +308,8 @@ __global__ void __launch_bounds__(256) RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const 
     }
     if (__ballot(!done) == 0ull) break;
 
-    if (!done) {
+    // (a lane whose fresh item has no samples — spt == 0 — goes straight back for the next one)
+    if (!done && !(need_sample && s_left <= 0)) {
       // ---- new sample: pixel jitter + Camera::get_ray ------------------------
       if (need_sample) {
         g.d = 0u;

@@ -174,4 +174,4 @@ def test_full_size_cover_properties(ctx):
                                 nranks=8, tile_rows=8)
     part, pst = ctx.render(scene, part_cfg)
     rows = rtow.local_rows(part_cfg)
-    assert len(rows) == 96 and np.array_equal(part, img[rows])
+    assert len(rows) == 104 and np.array_equal(part, img[rows])
