@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the path-tracing hot path on the RTOW cover scene.
+
+A "step" is one full render of the workload: every rank traces its strips of the
+image with the HIP kernels (scene already resident in HBM), and for N > 1 the
+framebuffer strips are gathered to rank 0 with ONE torch.distributed gather
+(backend nccl = RCCL over xGMI) and reassembled on the device.
+
+Workload (BASELINE.json configs):
+  N = 1 : configs[1]  cover scene (486 spheres), 1200x800, 100 spp, 50 bounces
+  N > 1 : configs[2]  same scene, 500 spp, tile-split over N GPUs + RCCL gather
+Both use 10 samples per work item (nstreams = spp / 10), f64 arithmetic (the
+reference is all-fp64), the fast (FMA-contracted) kernel build and seed 1.
+
+One JSON line on rank 0, with
+  roofline     — SURVEY.md §8d's streaming model: algorithmic bytes per launch =
+                 ceil(segments/64) * N_prim * 32 B + W*H*24 B, divided by the trace
+                 kernel's mean duration measured with HIP events on the launch
+                 stream inside the timed region; peak = 8 TB/s HBM.  The scene is
+                 cache/SGPR resident, so this is a VALU-bound kernel: roofline_valu
+                 gives the f64 vector-FLOP view next to it.
+  cpu_baseline — oracle/ (the CPU restatement of the reference's sample loop, same
+                 Philox stream) timed on this host's cores on a bounded sample of
+                 the same workload (same scene and resolution, fewer spp).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "raytracing-one-weekend_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import rtow  # noqa: E402
+
+W, ASPECT, DEPTH, SEED = 1200, 1.5, 50, 1
+SAMPLES_PER_ITEM = 10
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+F64_VALU_PEAK_TF = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+BYTES_PER_SPHERE = 32    # cx cy cz r^2 as f64 (16 B in f32, doubled for f64)
+FLOPS_PER_SPHERE_TEST = 23  # to the discriminant reject (src/common-model.cpp:70-75)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--precision", choices=["fast", "strict"], default="fast")
+    ap.add_argument("--kernel", choices=["auto", "brute", "bvh"], default="auto")
+    ap.add_argument("--moving", action="store_true", help="moving-sphere variant of the cover scene")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, height, seconds):
+    """Time the oracle (kind 'port') on this host: same scene/resolution, reduced spp."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import orc
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cal = rtow.make_config(W, height, 1, 1, DEPTH, seed=SEED)
+    t0 = time.perf_counter()
+    orc.render(scene, cal, orc.RNG_PHILOX, nthreads=cores)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    spp = int(max(1, min(64, seconds / dt)))
+    cfg = rtow.make_config(W, height, spp, 1, DEPTH, seed=SEED)
+    t0 = time.perf_counter()
+    _, st = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(st.samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores,
+        "kind": "port",
+        "sample": f"cover scene {W}x{height}, {spp} spp of the workload's spp, 50 bounces, "
+                  f"oracle/ (Philox stream) on {cores} threads, {dt:.1f} s",
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    H = rtow.image_height(W, ASPECT)
+    spp = a.spp or (100 if world == 1 else 500)
+    nstreams = max(1, spp // SAMPLES_PER_ITEM)
+    tile_rows = 4 if H % (4 * world) == 0 else 8
+    precision = rtow.F64_FAST if a.precision == "fast" else rtow.F64_STRICT
+    kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH}[a.kernel]
+    cfg = rtow.make_config(W, H, spp, nstreams, DEPTH, seed=SEED, precision=precision,
+                           kernel=kernel, rank=rank, nranks=world, tile_rows=tile_rows)
+
+    scene = rtow.HostScene.cover(11, ASPECT, a.moving)  # default mt19937 seed: 486 / 485 prims
+    n_prims = scene.c.n_prims
+    ctx = rtow.Context(local_rank)
+    ctx.upload(scene)  # scene resident in HBM before the timed region
+
+    rows = rtow.local_rows(cfg)
+    max_rows = max(len(rtow.local_rows(rtow.make_config(W, H, spp, nstreams, DEPTH, rank=r,
+                                                        nranks=world, tile_rows=tile_rows)))
+                   for r in range(world))
+    local = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev)
+    image = torch.zeros((H, W, 3), dtype=torch.float64, device=dev) if rank == 0 else None
+    gathered = ([torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None)
+    row_index = None
+    if rank == 0 and world > 1:
+        row_index = [torch.tensor(rtow.local_rows(rtow.make_config(W, H, spp, nstreams, DEPTH, rank=r,
+                                                                   nranks=world, tile_rows=tile_rows)),
+                                  device=dev, dtype=torch.long) for r in range(world)]
+    stream = torch.cuda.current_stream(dev)
+
+    def step(want_stats=False):
+        st = ctx.render_device(cfg, local.data_ptr(), stream.cuda_stream, want_stats)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)  # the one collective: framebuffer strips -> rank 0
+            if rank == 0:
+                for r in range(world):
+                    image.index_copy_(0, row_index[r], gathered[r][: row_index[r].numel()])
+        return st
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    st0 = step(want_stats=True)  # also sizes the workspace (allocation outside the timed region)
+    for _ in range(max(a.warmup - 1, 0)):
+        step()
+    fence()
+    ctx_lib = rtow.lib()
+    import ctypes as C
+    ctx_lib.rtow_profile_collect(ctx._h, None, None)  # reset the event ring
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kms, nl = C.c_double(), C.c_int32()
+    rtow.check(ctx_lib.rtow_profile_collect(ctx._h, C.byref(kms), C.byref(nl)), "profile_collect")
+    kernel_ms = kms.value / max(nl.value, 1)
+
+    # max over ranks of the step time; sums of per-rank work
+    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    work = torch.tensor([float(st0.samples), float(st0.segments)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(work, op=dist.ReduceOp.SUM)
+    elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
+    samples, segments = float(work[0]), float(work[1])
+
+    if rank == 0:
+        spp_eff = rtow.spp_effective(cfg)
+        assert samples == W * H * spp_eff, (samples, W * H * spp_eff)
+        ms_per_step = elapsed / a.steps * 1e3
+        value = samples / (elapsed / a.steps) / 1e6
+        # dominant kernel on THIS rank (rank 0): algorithmic bytes of its launch / its duration
+        seg0 = float(st0.segments)
+        alg_bytes = math.ceil(seg0 / 64) * n_prims * BYTES_PER_SPHERE + len(rows) * W * 24
+        alg_flops = seg0 * n_prims * FLOPS_PER_SPHERE_TEST
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        prof = ROOT / "profiles" / "r01_hbm_traffic.json"
+        if prof.exists():
+            try:
+                pj = json.loads(prof.read_text())
+                if pj.get("workload_spp") == spp and pj.get("n_gpus") == world:
+                    traffic = pj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Msamples/sec (W×H×spp) on cover scene; achieved HBM GB/s vs peak",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"RTOW cover scene ({n_prims} prims, {'moving' if a.moving else 'static'}) "
+                            f"{W}x{H}, {spp} spp, {DEPTH} bounces"
+                            + ("" if world == 1 else f", {tile_rows}-row strips over {world} GPUs + 1 RCCL gather"),
+                "baseline_config": "configs[1]" if (world == 1 and spp == 100) else
+                                   ("configs[2]" if spp == 500 else "custom"),
+                "spp_effective": spp_eff, "samples_per_item": spp // nstreams, "nstreams": nstreams,
+                "seed": SEED, "precision": a.precision,
+                "kernel": {1: "stream(brute-force, scalar-load broadcast)", 2: "bvh"}[st0.kernel_used],
+                "segments_per_sample": round(segments / samples, 4),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": "rtow_trace_" + a.precision, "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "model": "ceil(segments/64)*N_prim*32B + rows*W*24B (SURVEY.md §8d, f64 records)",
+            },
+            "roofline_valu": {
+                "bound": "valu_f64", "achieved": round(alg_flops / (kernel_ms * 1e-3) / 1e12, 3),
+                "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(alg_flops / (kernel_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TF, 5),
+                "model": "segments*N_prim*23 flop (sphere test to the discriminant reject)",
+            },
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, H, a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

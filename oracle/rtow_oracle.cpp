@@ -16,8 +16,12 @@
 //   MtGlobal  — the reference's process-global default-seeded std::mt19937 and
 //               libstdc++'s uniform_real_distribution mapping
 //               (src/random-utils.cpp:6-13): two 32-bit draws per double.
-//   PhiloxDraw— the device path's counter-based stream: draw d of sample s of
-//               pixel p is a pure function of (seed, p, s, d).
+//   PhiloxDraw— the device path's counter-based stream.  Random numbers are drawn
+//               in REQUESTS (the draw sites of the reference: pixel jitter = 2
+//               doubles, one disk candidate = 2, shutter time = 1, one unit-ball
+//               candidate = 3, the dielectric coin = 1); request r of sample s of
+//               pixel p is ONE Philox4x32-10 block, counter (r, s, p, 0), key =
+//               seed — a pure function of (seed, p, s, r).
 
 #include "rtow_oracle.h"
 
@@ -129,6 +133,7 @@ struct MtGlobal {
     return canonical_from_words(w0, w1);
   }
   void begin_sample(uint32_t, uint32_t) {}
+  void request(int) {}  // the global stream has no request structure
 };
 
 // Philox4x32-10 (Salmon et al., SC'11), the device path's generator.
@@ -155,28 +160,42 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
   out[3] = c3;
 }
 
-// Draw d of (pixel, sample): block d>>1 of counter (block, sample, pixel, 0),
-// words {0,1} for even d and {2,3} for odd d, mapped like the reference's doubles.
-inline double philox_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t d) {
-  uint32_t ctr[4] = {d >> 1, sample, pixel, 0u};
-  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  uint32_t o[4];
-  philox4x32_10(ctr, key, o);
-  return (d & 1u) ? canonical_from_words(o[2], o[3]) : canonical_from_words(o[0], o[1]);
-}
-
+// One request = one block.  1 or 2 doubles: words {0,1} and {2,3}, each pair mapped
+// like the reference's doubles (53 significant bits).  3 doubles: 42 bits each —
+// word k plus 10 bits of word 3 — which is exact in a double and never 1.0.
 struct PhiloxDraw {
   uint64_t seed = 0;
-  uint32_t pixel = 0, sample = 0, d = 0;
+  uint32_t pixel = 0, sample = 0, r = 0;
   uint64_t ndraws = 0;
-  double canonical() {
-    ++ndraws;
-    return philox_double(seed, pixel, sample, d++);
-  }
+  double buf[3];
+  int have = 0, pos = 0;
   void begin_sample(uint32_t p, uint32_t s) {
     pixel = p;
     sample = s;
-    d = 0;
+    r = 0;
+    have = pos = 0;
+  }
+  void request(int n) {
+    uint32_t ctr[4] = {r++, sample, pixel, 0u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    philox4x32_10(ctr, key, o);
+    if (n <= 2) {
+      buf[0] = canonical_from_words(o[0], o[1]);
+      buf[1] = canonical_from_words(o[2], o[3]);
+    } else {
+      const double s42 = 0x1p-42;
+      buf[0] = ((double)o[0] + (double)(o[3] & 1023u) * 4294967296.0) * s42;
+      buf[1] = ((double)o[1] + (double)((o[3] >> 10) & 1023u) * 4294967296.0) * s42;
+      buf[2] = ((double)o[2] + (double)((o[3] >> 20) & 1023u) * 4294967296.0) * s42;
+    }
+    have = n;
+    pos = 0;
+  }
+  double canonical() {
+    if (pos >= have) std::abort();  // a draw outside a request: oracle bug
+    ++ndraws;
+    return buf[pos++];
   }
 };
 
@@ -198,6 +217,7 @@ inline V3 random_vec3(R &rng, double lo = 0.0, double hi = 1.0) {
 template <class R>
 inline V3 random_in_unit_sphere(R &rng) {
   for (;;) {
+    rng.request(3);
     V3 v = random_vec3(rng);
     if (dot(v, v) >= 1) continue;
     return v;
@@ -213,6 +233,7 @@ inline V3 random_unit_vector(R &rng) {
 template <class R>
 inline V3 random_in_unit_disk(R &rng) {
   for (;;) {
+    rng.request(2);
     double py = random_double(rng, -1, 1);
     double px = random_double(rng, -1, 1);
     V3 p{px, py, 0};
@@ -352,6 +373,12 @@ inline bool triangle_hit(const Ray &r, double tmin, double tmax, V3 A, V3 B, V3 
 struct Counters {
   uint64_t segments = 0, prim_tests = 0, node_tests = 0;
 };
+
+// optional ray log (single-threaded renders only): one record of 12 doubles per segment
+// {pixel, sample, segment index, ox,oy,oz, dx,dy,dz, time, t_hit (inf = miss), prim}
+double *g_raylog = nullptr;
+uint64_t g_raylog_cap = 0, g_raylog_n = 0;
+thread_local uint32_t g_cur_pixel = 0, g_cur_sample = 0, g_cur_seg = 0;
 
 struct World {
   std::vector<Prim> prims;  // insertion order, then permuted in place by the BVH build
@@ -517,6 +544,7 @@ bool scatter_dielectric(const Material &m, const Ray &rin, const Hit &rec, R &rn
   double ratio = rec.front ? (1.0 / m.ir) : m.ir;
   bool cannot_refract = ratio * sin_theta > 1.0;
   V3 direction;
+  if (!cannot_refract) rng.request(1);  // the coin is drawn only if refraction is possible
   if (cannot_refract || reflectance(cos_theta, ratio) > random_double(rng))
     direction = reflect(unit, rec.normal);
   else
@@ -545,7 +573,18 @@ template <class R>
 V3 ray_color(const World &w, const Bvh &b, const Ray &ray, long max_depth, R &rng, Counters &cnt) {
   ++cnt.segments;
   Hit hit;
-  if (bvh_hit(w, b, b.root, ray, 0.001, std::numeric_limits<double>::infinity(), hit, cnt)) {
+  const bool did_hit =
+      bvh_hit(w, b, b.root, ray, 0.001, std::numeric_limits<double>::infinity(), hit, cnt);
+  if (g_raylog && g_raylog_n < g_raylog_cap) {
+    double *r = g_raylog + 12 * g_raylog_n++;
+    r[0] = g_cur_pixel; r[1] = g_cur_sample; r[2] = g_cur_seg++;
+    r[3] = ray.o.x; r[4] = ray.o.y; r[5] = ray.o.z;
+    r[6] = ray.d.x; r[7] = ray.d.y; r[8] = ray.d.z;
+    r[9] = ray.time;
+    r[10] = did_hit ? hit.at : std::numeric_limits<double>::infinity();
+    r[11] = did_hit ? (double)w.prims[hit.prim].cls_index : -1.0;
+  }
+  if (did_hit) {
     if (max_depth <= 0) return {0, 0, 0};
     Scatter sc;
     if (scatter(w, ray, hit, rng, sc))
@@ -564,6 +603,7 @@ Ray camera_get_ray(const rtow_camera_t &c, double s, double t, R &rng) {
   V3 offset = load3(c.u) * rd.x + load3(c.v) * rd.y;
   V3 from = load3(c.origin) + offset;
   V3 direction = load3(c.lower_left_corner) + s * load3(c.horizontal) + t * load3(c.vertical) - from;
+  rng.request(1);
   double when = random_double(rng, c.t0, c.t1);
   return Ray{from, direction, when};
 }
@@ -715,6 +755,7 @@ template <class R>
 inline V3 trace_sample(const World &w, const Bvh &bvh, const rtow_config_t &cfg, int i, int j,
                        R &rng, Counters &cnt) {
   int from_top_i = cfg.image_height - i - 1;
+  rng.request(2);
   double u = (j + random_double(rng)) / (cfg.image_width - 1);
   double v = (from_top_i + random_double(rng)) / (cfg.image_height - 1);
   Ray r = camera_get_ray(w.cam, u, v, rng);
@@ -727,6 +768,14 @@ inline V3 trace_sample(const World &w, const Bvh &bvh, const rtow_config_t &cfg,
 extern "C" {
 
 void orc_mt_reset(void) { the_generator().seed(5489u); }
+
+// Ray log for offline experiments (scripts/sim_*.py); pass NULL to switch it off.
+void orc_set_raylog(double *buf, uint64_t capacity_records) {
+  g_raylog = buf;
+  g_raylog_cap = capacity_records;
+  g_raylog_n = 0;
+}
+uint64_t orc_raylog_count(void) { return g_raylog_n; }
 
 void orc_mt_burn(uint64_t n) {
   MtGlobal g;
@@ -742,8 +791,15 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   philox4x32_10(ctr, key, out);
 }
 
-double orc_philox_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw) {
-  return philox_double(seed, pixel, sample, draw);
+// k-th double (k < n) of request `request` of n doubles
+double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t request, int n,
+                          int k) {
+  PhiloxDraw g;
+  g.seed = seed;
+  g.begin_sample(pixel, sample);
+  g.r = request;
+  g.request(n);
+  return g.buf[k];
 }
 
 // lots_of_balls(), src/main.cpp:23-83.
@@ -932,6 +988,9 @@ int orc_render(const rtow_scene_t *scene, const rtow_config_t *cfg, int rng_mode
             V3 partial{0, 0, 0};
             for (int s = 0; s < spt; ++s) {
               rng.begin_sample(pixel_id, (uint32_t)(k * spt + s));
+              g_cur_pixel = pixel_id;
+              g_cur_sample = (uint32_t)(k * spt + s);
+              g_cur_seg = 0;
               partial = partial + trace_sample(w, bvh, *cfg, i, j, rng, cnt);
             }
             global = partial + global;

@@ -54,9 +54,16 @@ int orc_ppm(const double *rgb_sums, int width, int height, int spp_effective, ch
             uint64_t *out_len);
 void orc_free(void *p);
 
+/* Optional log of every traced segment (12 doubles each: pixel, sample, segment,
+ * origin xyz, direction xyz, time, t_hit or inf, class index of the hit primitive);
+ * single-threaded Philox renders only.  Used by scripts/sim_traversal.py. */
+void orc_set_raylog(double *buf, uint64_t capacity_records);
+uint64_t orc_raylog_count(void);
+
 /* Function-level probes (for unit tests). */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-double orc_philox_double(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t draw);
+double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t request, int n,
+                          int k);
 double orc_mt_random_double(double a, double b);
 /* returns 1 on hit and writes t, point[3], normal[3], front_facing */
 int orc_sphere_hit(const double center[3], double radius, const double ro[3], const double rd[3],

@@ -1,4 +1,5 @@
-// rtow_bvh.h — host build of the device BVH (binned SAH, BVH2, DFS layout).
+// rtow_bvh.h — host build of the device BVH (binned SAH, BVH2) and of the scene
+// image the BVH kernel walks (threaded depth-first layout, padded f32 boxes).
 //
 // This is NOT the reference's tree (src/render.cpp:73-110 splits at the median
 // of one heuristic axis and unions every leaf box with the origin, so it culls
@@ -7,15 +8,18 @@
 // so the device is free to use a better one.  Boxes are padded so that rounding
 // in the slab test can never cull a primitive the exact hit test would accept.
 //
-// Layout: node 0 is the root; the two children of an inner node are adjacent
-// (left odd, right = left+1 even), so sibling(i) = i odd ? i+1 : i-1.
-//   box [n][6]  : min xyz, max xyz
+// Build output (HostBvh): node 0 is the root; the two children of an inner node are
+// adjacent (left, left+1).
+//   box [n][6]  : min xyz, max xyz (f64, exact primitive bounds)
 //   link[n][4]  : inner: {left child, 0, parent, 0}; leaf: {first, count, parent, 0}
 //   prim[]      : class-major primitive ids, leaf ranges contiguous
+// make_scene_image() then renumbers the nodes depth-first (the child nearer to the
+// camera first) and emits the 32-byte threaded node records of rtow_device.h.
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 namespace rtow {
@@ -56,8 +60,8 @@ struct Builder {
   std::vector<int32_t> order; // permutation being partitioned
   HostBvh *out;
   static constexpr int kBins = 16;
-  static constexpr int kLeafMax = 4;
-  static constexpr int kMaxDepth = 56;
+  int leaf_max = 4;                      // <= 7 (3 bits in the leaf word)
+  static constexpr int kSahDepth = 48;   // below this depth fall back to median splits
 
   void set_node(int idx, const Box &b, int a, int c, int parent) {
     for (int k = 0; k < 3; ++k) {
@@ -89,7 +93,7 @@ struct Builder {
       for (int i = lo; i < hi; ++i) out->prim.push_back(order[i]);
       set_node(idx, b, first, n, parent);
     };
-    if (n <= 1 || (depth >= kMaxDepth && n <= 64)) {
+    if (n <= 1) {
       make_leaf();
       return;
     }
@@ -141,7 +145,7 @@ struct Builder {
     int mid = -1;
     if (best_axis >= 0) {
       const double leaf_cost = b.half_area() * n;
-      if (n <= kLeafMax && best_cost >= leaf_cost) {
+      if (n <= leaf_max && best_cost >= leaf_cost) {
         make_leaf();
         return;
       }
@@ -154,9 +158,9 @@ struct Builder {
       });
       mid = (int)(it - order.begin());
     }
-    if (mid <= lo || mid >= hi || depth >= kMaxDepth - 8) {
+    if (mid <= lo || mid >= hi || depth >= kSahDepth) {
       // degenerate (coincident centroids) or too deep: median split on the widest axis
-      if (best_axis < 0 && n <= kLeafMax) {
+      if (best_axis < 0 && n <= leaf_max) {
         make_leaf();
         return;
       }
@@ -191,12 +195,14 @@ inline void pad_box(Box &b) {
 
 // sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
 inline void build_bvh(const std::vector<double> &sph, const std::vector<double> &sph_r,
-                      const std::vector<double> &mov, const std::vector<double> &tri, HostBvh &out) {
+                      const std::vector<double> &mov, const std::vector<double> &tri, HostBvh &out,
+                      int leaf_max = 4) {
   using namespace bvh_detail;
   const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
   const int n = ns + nm + nt;
   Builder B;
   B.out = &out;
+  B.leaf_max = std::min(std::max(leaf_max, 1), 7);
   B.pb.resize(n);
   B.cen.resize((size_t)n * 3);
   for (int i = 0; i < ns; ++i) {
@@ -240,6 +246,98 @@ inline void build_bvh(const std::vector<double> &sph, const std::vector<double> 
   out.prim.reserve(n);
   out.depth = 0;
   if (n > 0) B.build(0, 0, n, -1, 0);
+}
+
+// ---- scene image for the BVH kernel (layout: rtow_device.h, DevScene::blob) ----------
+struct SceneImage {
+  std::vector<unsigned char> blob;
+  uint32_t off_ids = 0, off_sph = 0, off_mov = 0, off_tri = 0;
+  int32_t n_nodes = 0;
+};
+
+inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
+                             const std::vector<double> &mov, const std::vector<double> &tri,
+                             const double cam_origin[3], SceneImage &img) {
+  const int n = (int)(bvh.link.size() / 4);
+  // the f32 slab test sees the ray origin and the planes rounded to f32: pad every box by
+  // more than that rounding can move a plane or an origin anywhere in the scene
+  double scale = 1.0;
+  for (int k = 0; k < 3; ++k) {
+    scale = std::max(scale, std::fabs(bvh.box[k]));
+    scale = std::max(scale, std::fabs(bvh.box[3 + k]));
+    scale = std::max(scale, std::fabs(cam_origin[k]));
+  }
+  // depth-first renumbering, nearer child (to the camera) first
+  std::vector<int> order;          // new index -> old index
+  std::vector<uint32_t> skip_new;  // new index -> skip link
+  order.reserve(n);
+  struct Frame { int node; uint32_t skip_slot; };
+  std::vector<int> stack;
+  std::vector<int> subtree_end(n, 0);
+  // iterative preorder
+  stack.push_back(0);
+  std::vector<int> newidx(n, -1);
+  while (!stack.empty()) {
+    const int nd = stack.back();
+    stack.pop_back();
+    newidx[nd] = (int)order.size();
+    order.push_back(nd);
+    if (bvh.link[(size_t)nd * 4 + 1] == 0) {
+      const int l = bvh.link[(size_t)nd * 4 + 0], r = l + 1;
+      auto dist2 = [&](int c) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) {
+          const double m = 0.5 * (bvh.box[(size_t)c * 6 + k] + bvh.box[(size_t)c * 6 + 3 + k]);
+          s += (m - cam_origin[k]) * (m - cam_origin[k]);
+        }
+        return s;
+      };
+      const bool left_first = dist2(l) <= dist2(r);
+      // push the second child first so the first child is numbered next
+      stack.push_back(left_first ? r : l);
+      stack.push_back(left_first ? l : r);
+    }
+  }
+  // subtree sizes (postorder over the new numbering: children have larger indices)
+  std::vector<int> size(n, 1);
+  for (int i = n - 1; i >= 0; --i) {
+    const int nd = order[i];
+    if (bvh.link[(size_t)nd * 4 + 1] == 0) {
+      const int l = bvh.link[(size_t)nd * 4 + 0];
+      size[i] = 1 + size[newidx[l]] + size[newidx[l + 1]];
+    }
+  }
+  const size_t nodes_bytes = (size_t)n * 32;
+  const size_t ids_bytes = ((bvh.prim.size() * 4 + 15) / 16) * 16;
+  img.off_ids = (uint32_t)nodes_bytes;
+  img.off_sph = (uint32_t)(nodes_bytes + ids_bytes);
+  img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
+  img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
+  const size_t total = (size_t)img.off_tri + tri.size() * 8;
+  img.blob.assign(((total + 15) / 16) * 16, 0);
+  img.n_nodes = n;
+  for (int i = 0; i < n; ++i) {
+    const int nd = order[i];
+    float rec[6];
+    for (int k = 0; k < 3; ++k) {
+      const double lo = bvh.box[(size_t)nd * 6 + k], hi = bvh.box[(size_t)nd * 6 + 3 + k];
+      const double pad = 1e-6 * scale + 1e-6 * std::max(std::fabs(lo), std::fabs(hi));
+      rec[k] = std::nextafterf((float)(lo - pad), -INFINITY);
+      rec[3 + k] = std::nextafterf((float)(hi + pad), INFINITY);
+    }
+    const uint32_t nxt = (uint32_t)(i + size[i]);
+    const uint32_t skip = nxt >= (uint32_t)n ? 0xffffffffu : nxt;
+    const int cnt = bvh.link[(size_t)nd * 4 + 1];
+    const uint32_t leaf = cnt > 0 ? ((uint32_t)bvh.link[(size_t)nd * 4 + 0] << 3) | (uint32_t)cnt : 0u;
+    unsigned char *dst = img.blob.data() + (size_t)i * 32;
+    std::memcpy(dst, rec, 24);
+    std::memcpy(dst + 24, &skip, 4);
+    std::memcpy(dst + 28, &leaf, 4);
+  }
+  if (!bvh.prim.empty()) std::memcpy(img.blob.data() + img.off_ids, bvh.prim.data(), bvh.prim.size() * 4);
+  if (!sph.empty()) std::memcpy(img.blob.data() + img.off_sph, sph.data(), sph.size() * 8);
+  if (!mov.empty()) std::memcpy(img.blob.data() + img.off_mov, mov.data(), mov.size() * 8);
+  if (!tri.empty()) std::memcpy(img.blob.data() + img.off_tri, tri.data(), tri.size() * 8);
 }
 
 }  // namespace rtow

@@ -41,7 +41,9 @@ int fail(int code, const char *fmt, ...) {
       return fail(RTOW_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;      // STREAM kernel workgroup
+constexpr int kBvhBlock = 512;   // BVH kernel workgroup (one LDS scene image per workgroup)
+constexpr unsigned kLdsLimit = 160u * 1024u;
 constexpr int kEventRing = 256;
 
 struct DevBuf {
@@ -85,11 +87,13 @@ struct rtow_ctx {
   rtow::DevCamera cam{};
   int n_prims = 0;
   // scene buffers
-  DevBuf sph, sph_r, mov, tri, prim_mat, mats, bvh_box, bvh_link, bvh_prim;
+  DevBuf sph, sph_r, mov, tri, prim_mat, mats, blob;
+  uint32_t blob_bytes = 0;
+  long long bvh_nodes = 0;
   // workspace
   DevBuf partials, stack, counters;
-  // occupancy (blocks per CU) per precision, filled lazily
-  int occ[2] = {0, 0};
+  // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet), LDS bytes
+  int occ[2][2] = {{0, 0}, {0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
   hipEvent_t ev[kEventRing][2];
   bool ev_ready = false;
@@ -132,8 +136,8 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->bvh_box,
-                    &c->bvh_link, &c->bvh_prim, &c->partials, &c->stack, &c->counters})
+  for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob,
+                    &c->partials, &c->stack, &c->counters})
     b->release();
   if (c->ev_ready) {
     for (int i = 0; i < kEventRing; ++i)
@@ -235,15 +239,21 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     d.kind = m.kind;
   }
 
-  // device BVH over the same records
+  // device BVH over the same records, packed with them into one scene image
   rtow::HostBvh bvh;
-  rtow::build_bvh(sph, sph_r, mov, tri, bvh);
+  int leaf_max = 4;
+  if (const char *e = std::getenv("RTOW_BVH_LEAF")) leaf_max = std::atoi(e);
+  rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max);
+  rtow::SceneImage img;
+  rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img);
 
   if ((rc = upload(c->sph, sph)) || (rc = upload(c->sph_r, sph_r)) || (rc = upload(c->mov, mov)) ||
       (rc = upload(c->tri, tri)) || (rc = upload(c->prim_mat, pmat)) || (rc = upload(c->mats, mats)) ||
-      (rc = upload(c->bvh_box, bvh.box)) || (rc = upload(c->bvh_link, bvh.link)) ||
-      (rc = upload(c->bvh_prim, bvh.prim)))
+      (rc = upload(c->blob, img.blob)))
     return rc;
+  c->blob_bytes = (uint32_t)img.blob.size();
+  c->bvh_nodes = img.n_nodes;
+  for (auto &o : c->occ) o[0] = o[1] = 0;
 
   rtow::DevScene &ds = c->ds;
   ds.sph = (const double *)c->sph.p;
@@ -256,10 +266,13 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   ds.n_mov = nm;
   ds.n_tri = nt;
   ds.n_mats = s->n_materials;
-  ds.bvh_box = (const double *)c->bvh_box.p;
-  ds.bvh_link = (const int32_t *)c->bvh_link.p;
-  ds.bvh_prim = (const int32_t *)c->bvh_prim.p;
-  ds.n_nodes = (int32_t)(bvh.link.size() / 4);
+  ds.blob = (const unsigned char *)c->blob.p;
+  ds.blob_bytes = c->blob_bytes;
+  ds.off_ids = img.off_ids;
+  ds.off_sph = img.off_sph;
+  ds.off_mov = img.off_mov;
+  ds.off_tri = img.off_tri;
+  ds.n_nodes = img.n_nodes;
   c->n_prims = ns + nm + nt;
 
   const rtow_camera_t &k = s->camera;
@@ -337,8 +350,12 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   if (n_items > 0xfffffff0ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
 
   int kernel = cfg->kernel;
-  if (kernel == RTOW_KERNEL_AUTO) kernel = RTOW_KERNEL_BRUTE;
+  // a handful of primitives is cheaper to stream than to walk
+  if (kernel == RTOW_KERNEL_AUTO) kernel = c->n_prims > 16 ? RTOW_KERNEL_BVH : RTOW_KERNEL_BRUTE;
   const bool strict = cfg->precision == RTOW_F64_STRICT;
+  const int block = kernel == RTOW_KERNEL_BVH ? kBvhBlock : kBlock;
+  // the scene image goes to LDS when one copy per workgroup fits (160 KiB per CU)
+  const unsigned lds_bytes = (kernel == RTOW_KERNEL_BVH && c->blob_bytes <= kLdsLimit) ? c->blob_bytes : 0u;
 
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
@@ -354,17 +371,18 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   }
 
   // grid: as many 256-lane blocks as stay resident, but no more than there are items
-  int &occ = c->occ[strict ? 0 : 1];
+  int &occ = c->occ[strict ? 0 : 1][kernel - 1];
   if (occ <= 0) {
-    occ = strict ? rtow::trace_occupancy_strict(kernel, kBlock) : rtow::trace_occupancy_fast(kernel, kBlock);
-    if (occ <= 0) return fail(RTOW_EHIP, "occupancy query failed");
+    occ = strict ? rtow::trace_occupancy_strict(kernel, block, lds_bytes)
+                 : rtow::trace_occupancy_fast(kernel, block, lds_bytes);
+    if (occ <= 0) return fail(RTOW_EHIP, "occupancy query failed (kernel %d, %u B of LDS)", kernel, lds_bytes);
     if (occ > 8) occ = 8;
   }
   long long grid = (long long)c->num_cus * occ;
-  const long long need_blocks = (long long)((n_items + kBlock - 1) / kBlock);
+  const long long need_blocks = (long long)((n_items + block - 1) / block);
   if (grid > need_blocks) grid = need_blocks;
   if (grid < 1) grid = 1;
-  const unsigned long long n_lanes = (unsigned long long)grid * kBlock;
+  const unsigned long long n_lanes = (unsigned long long)grid * block;
 
   const size_t depth_slots = (size_t)(cfg->max_child_rays > 0 ? cfg->max_child_rays : 1);
   if ((rc = c->partials.ensure((size_t)n_items * 3 * sizeof(double))) ||
@@ -397,8 +415,8 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   HIPCHK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), st));
   const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
   if (slot >= 0) HIPCHK(hipEventRecord(c->ev[slot][0], st));
-  int lrc = strict ? rtow::launch_trace_strict(P, kernel, (int)grid, kBlock, st)
-                   : rtow::launch_trace_fast(P, kernel, (int)grid, kBlock, st);
+  int lrc = strict ? rtow::launch_trace_strict(P, kernel, (int)grid, block, lds_bytes, st)
+                   : rtow::launch_trace_fast(P, kernel, (int)grid, block, lds_bytes, st);
   if (lrc != 0) return fail(RTOW_EHIP, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   if (slot >= 0) {
     HIPCHK(hipEventRecord(c->ev[slot][1], st));

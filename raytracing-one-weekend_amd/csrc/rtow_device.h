@@ -38,11 +38,16 @@ struct DevScene {
   const int32_t *prim_mat; // [n_prims]   material index by class-major id
   const DevMaterial *mats;
   int32_t n_sph, n_mov, n_tri, n_mats;
-  // flattened BVH (kernel RTOW_KERNEL_BVH)
-  const double *bvh_box;   // [n_nodes][6] min xyz max xyz
-  const int32_t *bvh_link; // [n_nodes][4] left right first count  (count>0 → leaf)
-  const int32_t *bvh_prim; // leaf → class-major primitive ids
-  int32_t n_nodes, pad_;
+  // scene image for the BVH kernel (kernel RTOW_KERNEL_BVH): one 16-byte aligned blob
+  //   [nodes n_nodes x 32 B][prim ids n_prims x 4 B][sph n x 32 B][mov n x 64 B][tri n x 96 B]
+  // node = { f32 lo[3], f32 hi[3], u32 skip, u32 leaf }: threaded (stackless) BVH in
+  // depth-first order — on a box hit an inner node continues at node+1, otherwise at
+  // `skip`; leaf != 0 encodes (first << 3 | count) into the prim-id section.
+  // The blob is copied into LDS by every workgroup when it fits (blob_in_lds).
+  const unsigned char *blob;
+  uint32_t blob_bytes;
+  uint32_t off_ids, off_sph, off_mov, off_tri;
+  int32_t n_nodes;
 };
 
 struct TraceParams {
@@ -71,10 +76,13 @@ struct ReduceParams {
 
 // launchers, one pair per arithmetic mode (separate translation units compiled
 // with -ffp-contract=off / -ffp-contract=fast)
-int launch_trace_strict(const TraceParams &p, int kernel, int grid, int block, void *stream);
-int launch_trace_fast(const TraceParams &p, int kernel, int grid, int block, void *stream);
-int trace_occupancy_strict(int kernel, int block);
-int trace_occupancy_fast(int kernel, int block);
+// `lds_bytes` > 0 selects the variant that stages the scene blob in LDS
+int launch_trace_strict(const TraceParams &p, int kernel, int grid, int block, unsigned lds_bytes,
+                        void *stream);
+int launch_trace_fast(const TraceParams &p, int kernel, int grid, int block, unsigned lds_bytes,
+                      void *stream);
+int trace_occupancy_strict(int kernel, int block, unsigned lds_bytes);
+int trace_occupancy_fast(int kernel, int block, unsigned lds_bytes);
 int launch_reduce(const ReduceParams &p, void *stream);
 
 }  // namespace rtow

@@ -14,20 +14,30 @@
 //     queue is empty, and the image does not depend on which lane traced what.
 //   * ray regeneration.  Each trip of the main loop advances every live lane by
 //     exactly one ray segment; a lane whose path ended starts its next sample in
-//     the same trip, so the closest-hit loop always runs on a full wave.
-//   * closest hit, streaming kernel: every lane tests every primitive.  The
-//     primitive index is wave-uniform, so each record is fetched with ONE scalar
-//     load into SGPRs and used directly as a VALU operand: the scene costs no
-//     VGPRs and no LDS bandwidth.
+//     the same trip, so the closest-hit step always runs on a full wave.
+//   * closest hit, two strategies with identical results:
+//       STREAM — every lane tests every primitive.  The primitive index is
+//         wave-uniform, so each record is fetched with ONE scalar load into SGPRs and
+//         used directly as a VALU operand: the scene costs no VGPRs, no LDS traffic.
+//       BVH — every lane walks a threaded (stackless, skip-link) BVH whose nodes and
+//         primitive records sit in LDS (one scene image per workgroup, staged with
+//         coalesced 16-byte loads).  Node boxes are f32 and padded, and the slab test
+//         is slackened, so culling is conservative; leaf primitives are tested with
+//         the same f64 code as STREAM, so the accepted (t, primitive) is the same.
+//         Leaves found during the walk are queued per lane and tested in a separate
+//         phase, so the box loop and the primitive loop are each SIMT-dense.
 //   * radiance.  The reference multiplies attenuations on the way back up the
 //     recursion, a1*(a2*(...*(an*sky))).  To reproduce that order bit for bit the
 //     lane records the material index of every bounce in a per-lane path stack in
 //     HBM ([bounce][lane], coalesced) and folds it from the end when the path
 //     escapes to the sky.  A path that ends black contributes an exact zero.
-//   * RNG: Philox4x32-10, counter (draw>>1, sample, pixel, 0), key = seed; the two
-//     64-bit halves of a block are consecutive draws, mapped to [0,1) exactly like
-//     libstdc++'s generate_canonical<double,53> maps two mt19937 words
-//     (src/random-utils.cpp:11-13).
+//   * RNG: Philox4x32-10 in REQUESTS — one block per draw site (pixel jitter: 2
+//     doubles, disk candidate: 2, shutter time: 1, unit-ball candidate: 3,
+//     dielectric coin: 1), counter (request, sample, pixel, 0), key = seed.  One
+//     block per request keeps the rejection loops free of per-lane parity
+//     divergence.  1-2 doubles map two words each like libstdc++'s
+//     generate_canonical<double,53> (src/random-utils.cpp:11-13); 3 doubles take 42
+//     bits each.
 //
 // In the strict build (-ffp-contract=off) every expression below has the operand
 // order of the reference expression it restates, f64 sqrt and division are the
@@ -51,7 +61,6 @@ namespace {
 // address space lets hipcc use scalar loads for wave-uniform indices.
 #define RTOW_CONST __attribute__((address_space(4)))
 typedef const RTOW_CONST double *cdptr;
-typedef const RTOW_CONST int32_t *ciptr;
 
 struct V3 {
   double x, y, z;
@@ -80,8 +89,7 @@ __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; 
 
 // ------------------------------------------------------------------ Philox ---
 struct Rng {
-  uint32_t pixel, sample, d;
-  uint32_t w2, w3;  // second half of the current block (valid when d is odd)
+  uint32_t pixel, sample, r;  // r = next request index of this sample
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -116,42 +124,45 @@ __device__ __forceinline__ double canonical_from_words(uint32_t w0, uint32_t w1)
   return r;
 }
 
-__device__ __forceinline__ double rng_canonical(Rng &g, uint32_t k0, uint32_t k1) {
-  uint32_t w0, w1;
-  if ((g.d & 1u) == 0u) {
-    uint32_t o0, o1, o2, o3;
-    philox4x32_10(g.d >> 1, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-    w0 = o0;
-    w1 = o1;
-    g.w2 = o2;
-    g.w3 = o3;
-  } else {
-    w0 = g.w2;
-    w1 = g.w3;
-  }
-  g.d += 1u;
-  return canonical_from_words(w0, w1);
+// one request of 1 or 2 canonical doubles
+__device__ __forceinline__ void rng_request2(Rng &g, uint32_t k0, uint32_t k1, double &a, double &b) {
+  uint32_t o0, o1, o2, o3;
+  philox4x32_10(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
+  a = canonical_from_words(o0, o1);
+  b = canonical_from_words(o2, o3);
 }
-
-// src/random-utils.cpp:11-13: canonical*(b-a)+a
-__device__ __forceinline__ double rng_range(Rng &g, uint32_t k0, uint32_t k1, double a, double b) {
-  return rng_canonical(g, k0, k1) * (b - a) + a;
+__device__ __forceinline__ double rng_request1(Rng &g, uint32_t k0, uint32_t k1) {
+  uint32_t o0, o1, o2, o3;
+  philox4x32_10(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
+  return canonical_from_words(o0, o1);
+}
+// one request of 3 canonical doubles, 42 bits each
+__device__ __forceinline__ V3 rng_request3(Rng &g, uint32_t k0, uint32_t k1) {
+  uint32_t o0, o1, o2, o3;
+  philox4x32_10(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
+  const double s42 = 0x1p-42;
+  V3 v;
+  v.x = ((double)o0 + (double)(o3 & 1023u) * 4294967296.0) * s42;
+  v.y = ((double)o1 + (double)((o3 >> 10) & 1023u) * 4294967296.0) * s42;
+  v.z = ((double)o2 + (double)((o3 >> 20) & 1023u) * 4294967296.0) * s42;
+  return v;
 }
 
 // src/random-utils.cpp:23-33: a point of [0,1)^3 inside the unit ball, not normalised
 __device__ __forceinline__ V3 rng_unit_vector(Rng &g, uint32_t k0, uint32_t k1) {
   V3 v;
   for (;;) {
-    v.x = rng_canonical(g, k0, k1);
-    v.y = rng_canonical(g, k0, k1);
-    v.z = rng_canonical(g, k0, k1);
+    v = rng_request3(g, k0, k1);
     if (dot(v, v) >= 1.0) continue;
     break;
   }
   return v;
 }
 
-// ------------------------------------------------------- closest hit: stream ---
+// -------------------------------------------------------- primitive hit tests ---
 struct Closest {
   double t;  // closest accepted root so far (the shrinking tmax of src/render.cpp:57-65)
   int prim;  // class-major primitive id, -1 = miss
@@ -196,11 +207,14 @@ __device__ __forceinline__ void triangle_test(V3 o, V3 d, V3 A, V3 e1, V3 e2, V3
   }
 }
 
+#define RTOW_TMIN 0.001  // src/render.cpp:33
+
+// ------------------------------------------------------- closest hit: STREAM ---
 __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, V3 d, double time) {
   Closest best;
   best.t = __builtin_huge_val();  // tmax = +inf, src/render.cpp:34
   best.prim = -1;
-  const double tmin = 0.001;  // src/render.cpp:33
+  const double tmin = RTOW_TMIN;
   const double a = dot(d, d);
   {
     cdptr g = (cdptr)sc.sph;
@@ -239,18 +253,144 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, 
   return best;
 }
 
+// ---------------------------------------------------------- closest hit: BVH ---
+extern __shared__ __align__(16) unsigned char rtow_lds[];
+
+// Scene image reader: LDS copy (ds_read_b128/b64) or the global blob (L1/L2).
+template <bool LDS>
+struct Image {
+  const unsigned char *g;
+  __device__ __forceinline__ float4 f4(uint32_t off) const {
+    if constexpr (LDS)
+      return *reinterpret_cast<const float4 *>(rtow_lds + off);
+    else
+      return *reinterpret_cast<const float4 *>(g + off);
+  }
+  __device__ __forceinline__ double2 d2(uint32_t off) const {
+    if constexpr (LDS)
+      return *reinterpret_cast<const double2 *>(rtow_lds + off);
+    else
+      return *reinterpret_cast<const double2 *>(g + off);
+  }
+  __device__ __forceinline__ uint32_t u32(uint32_t off) const {
+    if constexpr (LDS)
+      return *reinterpret_cast<const uint32_t *>(rtow_lds + off);
+    else
+      return *reinterpret_cast<const uint32_t *>(g + off);
+  }
+};
+
+__device__ __forceinline__ float safe_inv(float d) {
+  // axis-parallel rays: a huge finite reciprocal keeps the fma slab form free of NaNs
+  const float big = 1e30f;
+  return fabsf(d) < 1e-30f ? (__builtin_signbitf(d) ? -big : big) : 1.0f / d;
+}
+
+template <bool LDS>
+__device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, uint32_t leaf,
+                                          V3 o, V3 d, double a, double time, Closest &best,
+                                          uint32_t &nprim) {
+  const uint32_t first = leaf >> 3, count = leaf & 7u;
+  for (uint32_t k = 0; k < count; ++k) {
+    const int id = (int)im.u32(sc.off_ids + 4u * (first + k));
+    ++nprim;
+    if (id < sc.n_sph) {
+      const uint32_t off = sc.off_sph + 32u * (uint32_t)id;
+      const double2 p0 = im.d2(off), p1 = im.d2(off + 16u);
+      sphere_test(o, d, a, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+    } else if (id < sc.n_sph + sc.n_mov) {
+      const uint32_t off = sc.off_mov + 64u * (uint32_t)(id - sc.n_sph);
+      const double2 p0 = im.d2(off), p1 = im.d2(off + 16u), p2 = im.d2(off + 32u), p3 = im.d2(off + 48u);
+      const double cx = p0.x + time * p1.y;
+      const double cy = p0.y + time * p2.x;
+      const double cz = p1.x + time * p2.y;
+      sphere_test(o, d, a, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
+    } else {
+      const uint32_t off = sc.off_tri + 96u * (uint32_t)(id - sc.n_sph - sc.n_mov);
+      const double2 q0 = im.d2(off), q1 = im.d2(off + 16u), q2 = im.d2(off + 32u),
+                    q3 = im.d2(off + 48u), q4 = im.d2(off + 64u), q5 = im.d2(off + 80u);
+      triangle_test(o, d, V3{q0.x, q0.y, q1.x}, V3{q1.y, q2.x, q2.y}, V3{q3.x, q3.y, q4.x},
+                    V3{q4.y, q5.x, q5.y}, id, RTOW_TMIN, best);
+    }
+  }
+}
+
+template <bool LDS>
+__device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const DevScene &sc, V3 o,
+                                                   V3 d, double time, bool active, uint32_t &nnode,
+                                                   uint32_t &nprim) {
+  Closest best;
+  best.t = __builtin_huge_val();
+  best.prim = -1;
+  const double a = dot(d, d);
+  // f32 copy of the ray for the (conservative) box tests
+  const float ix = safe_inv((float)d.x), iy = safe_inv((float)d.y), iz = safe_inv((float)d.z);
+  const float oix = (float)o.x * ix, oiy = (float)o.y * iy, oiz = (float)o.z * iz;
+  const float tmin32 = 0.0009f;   // < RTOW_TMIN
+  const float slack = 1.00002f;   // relative slack on the far side of the interval
+  float tmax32 = __builtin_huge_valf();
+  const uint32_t END = 0xffffffffu;
+  uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
+  uint32_t q0 = 0u, q1 = 0u;  // queued leaves (0 = empty)
+  for (;;) {
+    if (node != END) {
+      const float4 r0 = im.f4(node * 32u), r1 = im.f4(node * 32u + 16u);
+      ++nnode;
+      const float ax = fmaf(r0.x, ix, -oix), bx = fmaf(r0.w, ix, -oix);
+      const float ay = fmaf(r0.y, iy, -oiy), by = fmaf(r1.x, iy, -oiy);
+      const float az = fmaf(r0.z, iz, -oiz), bz = fmaf(r1.y, iz, -oiz);
+      const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
+      const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax32));
+      const bool hit = tnear <= tfar * slack;
+      const uint32_t skip = __float_as_uint(r1.z), leaf = __float_as_uint(r1.w);
+      if (hit && leaf != 0u) {
+        if (q0 == 0u)
+          q0 = leaf;
+        else
+          q1 = leaf;
+      }
+      node = (hit && leaf == 0u) ? node + 1u : skip;
+    }
+    const bool any_walking = __any(node != END);
+    if (__any(q1 != 0u) || !any_walking) {
+      // leaf phase: every lane tests the primitives of the leaves it queued
+      if (q0 != 0u) leaf_test(im, sc, q0, o, d, a, time, best, nprim);
+      if (q1 != 0u) leaf_test(im, sc, q1, o, d, a, time, best, nprim);
+      q0 = 0u;
+      q1 = 0u;
+      // shrink the f32 interval (rounded up: never below the f64 value)
+      tmax32 = __double2float_ru(best.t);
+      if (!any_walking) break;
+    }
+  }
+  return best;
+}
+
 // --------------------------------------------------------------- the kernel ---
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-template <int KERNEL>
-__global__ void __launch_bounds__(256) RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const TraceParams P) {
+// KERNEL: 1 = STREAM, 2 = BVH;  LDS: scene image staged in LDS (BVH only)
+template <int KERNEL, bool LDS>
+__global__ void __launch_bounds__(KERNEL == 2 ? 512 : 256)
+    RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const TraceParams P) {
   const DevScene &sc = P.sc;
   const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
   const unsigned lane = lane_id();
   const uint32_t lane_g = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t npix_local = (uint32_t)P.local_rows * (uint32_t)P.W;
+
+  Image<LDS> im;
+  im.g = sc.blob;
+  if constexpr (KERNEL == 2 && LDS) {
+    // stage the scene image: coalesced 16-byte loads, 16-byte LDS stores
+    const uint4 *src = reinterpret_cast<const uint4 *>(sc.blob);
+    uint4 *dst = reinterpret_cast<uint4 *>(rtow_lds);
+    const uint32_t n16 = sc.blob_bytes / 16u;
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
 
   // per-lane state
   bool done = false;
@@ -264,8 +404,8 @@ __global__ void __launch_bounds__(256) RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const 
   double rtime = 0.0;
   int depth = 0;              // remaining child rays
   int nb = 0;                 // bounces recorded on the path stack
-  Rng g = {0, 0, 0, 0, 0};
-  uint32_t nseg = 0;
+  Rng g = {0, 0, 0};
+  uint32_t nseg = 0, nnode = 0, nprim = 0;
 
   for (;;) {
     // ---- item bookkeeping ---------------------------------------------------
@@ -309,37 +449,51 @@ __global__ void __launch_bounds__(256) RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const 
     if (__ballot(!done) == 0ull) break;
 
     // (a lane whose fresh item has no samples — spt == 0 — goes straight back for the next one)
-    if (!done && !(need_sample && s_left <= 0)) {
-      // ---- new sample: pixel jitter + Camera::get_ray ------------------------
-      if (need_sample) {
-        g.d = 0u;
-        // src/render.cpp:158-159
-        const int from_top_i = P.H - (int)gi - 1;
-        const double u = ((double)(int)j + rng_canonical(g, k0, k1)) / (double)(P.W - 1);
-        const double v = ((double)from_top_i + rng_canonical(g, k0, k1)) / (double)(P.H - 1);
-        // src/common-model.cpp:156-167; disk sample: y draws first (random-utils.cpp:36)
-        double px, py;
-        for (;;) {
-          py = rng_range(g, k0, k1, -1.0, 1.0);
-          px = rng_range(g, k0, k1, -1.0, 1.0);
-          if (px * px + py * py + 0.0 * 0.0 >= 1.0) continue;
-          break;
-        }
-        const double rdx = P.cam.lens_radius * px, rdy = P.cam.lens_radius * py;
-        const V3 offset = ld3(P.cam.u) * rdx + ld3(P.cam.v) * rdy;
-        const V3 from = ld3(P.cam.origin) + offset;
-        rd = ld3(P.cam.llc) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - from;
-        ro = from;
-        rtime = rng_range(g, k0, k1, P.cam.t0, P.cam.t1);
-        depth = P.max_child_rays;
-        nb = 0;
-        need_sample = false;
+    const bool live = !done && !(need_sample && s_left <= 0);
+
+    // ---- new sample: pixel jitter + Camera::get_ray ----------------------------
+    if (live && need_sample) {
+      g.r = 0u;
+      // src/render.cpp:158-159
+      const int from_top_i = P.H - (int)gi - 1;
+      double ju, jv;
+      rng_request2(g, k0, k1, ju, jv);
+      const double u = ((double)(int)j + ju) / (double)(P.W - 1);
+      const double v = ((double)from_top_i + jv) / (double)(P.H - 1);
+      // src/common-model.cpp:156-167; disk sample: y draws first (random-utils.cpp:36)
+      double px, py;
+      for (;;) {
+        double c0, c1;
+        rng_request2(g, k0, k1, c0, c1);
+        py = c0 * (1.0 - -1.0) + -1.0;
+        px = c1 * (1.0 - -1.0) + -1.0;
+        if (px * px + py * py + 0.0 * 0.0 >= 1.0) continue;
+        break;
       }
+      const double rdx = P.cam.lens_radius * px, rdy = P.cam.lens_radius * py;
+      const V3 offset = ld3(P.cam.u) * rdx + ld3(P.cam.v) * rdy;
+      const V3 from = ld3(P.cam.origin) + offset;
+      rd = ld3(P.cam.llc) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - from;
+      ro = from;
+      rtime = rng_request1(g, k0, k1) * (P.cam.t1 - P.cam.t0) + P.cam.t0;
+      depth = P.max_child_rays;
+      nb = 0;
+      need_sample = false;
+    }
 
-      // ---- one ray segment: closest hit --------------------------------------
+    // ---- one ray segment: closest hit --------------------------------------------
+    Closest best;
+    best.t = 0.0;
+    best.prim = -1;
+    if constexpr (KERNEL == 2) {
+      // the walk uses wave votes, so every lane of the wave enters it
+      best = closest_hit_bvh<LDS>(im, sc, ro, rd, rtime, live, nnode, nprim);
+    } else {
+      if (live) best = closest_hit_stream(sc, ro, rd, rtime);
+    }
+
+    if (live) {
       ++nseg;
-      const Closest best = closest_hit_stream(sc, ro, rd, rtime);
-
       if (best.prim >= 0) {
         if (depth <= 0) {
           need_sample = true;  // src/render.cpp:115: black
@@ -387,7 +541,7 @@ __global__ void __launch_bounds__(256) RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const 
               const double x = 1.0 - cos_theta;
               const double x2 = x * x;
               const double R = r0 + (1.0 - r0) * (x2 * x2 * x);
-              refl = R > rng_canonical(g, k0, k1);
+              refl = R > rng_request1(g, k0, k1);
             }
             dirbase = refl ? reflect(unit, normal) : refract(unit, normal, ratio);
           } else if (kind == 1) {
@@ -433,28 +587,60 @@ __global__ void __launch_bounds__(256) RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const 
     }
   }
 
-  // stats: one atomic per wave
-  unsigned long long tot = nseg;
+  // stats: one atomic per wave and counter
+  unsigned long long t0 = nseg, t1 = nprim, t2 = nnode;
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) tot += __shfl_down(tot, off);
-  if (lane == 0) atomicAdd(&P.counters[1], tot);
+  for (int off = 32; off >= 1; off >>= 1) {
+    t0 += __shfl_down(t0, off);
+    t1 += __shfl_down(t1, off);
+    t2 += __shfl_down(t2, off);
+  }
+  if (lane == 0) {
+    atomicAdd(&P.counters[1], t0);
+    if (KERNEL == 2) {
+      atomicAdd(&P.counters[2], t1);
+      atomicAdd(&P.counters[3], t2);
+    }
+  }
 }
 
 }  // namespace
 
 int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int grid, int block,
-                                         void *stream) {
-  (void)kernel;
-  hipLaunchKernelGGL((RTOW_CAT(rtow_trace_, RTOW_SUFFIX) < 1 >), dim3(grid), dim3(block), 0,
-                     (hipStream_t)stream, p);
+                                         unsigned lds_bytes, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (kernel == 2) {
+    if (lds_bytes > 0) {
+      auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true>;
+      if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+      }
+      hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, st, p);
+    } else {
+      hipLaunchKernelGGL((RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, false>), dim3(grid), dim3(block), 0, st, p);
+    }
+  } else {
+    hipLaunchKernelGGL((RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<1, false>), dim3(grid), dim3(block), 0, st, p);
+  }
   return (int)hipGetLastError();
 }
 
-int RTOW_CAT(trace_occupancy_, RTOW_SUFFIX)(int kernel, int block) {
-  (void)kernel;
+int RTOW_CAT(trace_occupancy_, RTOW_SUFFIX)(int kernel, int block, unsigned lds_bytes) {
   int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-      &nb, RTOW_CAT(rtow_trace_, RTOW_SUFFIX) < 1 >, block, 0);
+  hipError_t e;
+  if (kernel == 2 && lds_bytes > 0) {
+    auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true>;
+    if (lds_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, block, lds_bytes);
+  } else if (kernel == 2) {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, false>, block, 0);
+  } else {
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<1, false>, block, 0);
+  }
   if (e != hipSuccess) return -1;
   return nb;
 }

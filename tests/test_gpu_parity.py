@@ -37,13 +37,18 @@ def to8(img, spp):
     return (256 * np.clip(np.sqrt(img / spp), 0.0, 0.999)).astype(np.int32)
 
 
+KERNELS = {"stream": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH}
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
 @pytest.mark.parametrize("name", list(CASES))
-def test_strict_is_bit_identical_to_oracle_and_golden(ctx, name):
+def test_strict_is_bit_identical_to_oracle_and_golden(ctx, name, kernel):
     kind, args, w, aspect, spp, ns, depth, seed = CASES[name]
     scene = make_scene(kind, args)
     cfg = rtow.make_config(w, rtow.image_height(w, aspect), spp, ns, depth, seed=seed,
-                           precision=rtow.F64_STRICT, kernel=rtow.KERNEL_BRUTE)
+                           precision=rtow.F64_STRICT, kernel=KERNELS[kernel])
     img, st = ctx.render(scene, cfg)
+    assert st.kernel_used == KERNELS[kernel]
     ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
     assert img.shape == ref.shape
     assert np.array_equal(img, ref), f"{int((img != ref).sum())} of {img.size} values differ"
@@ -53,12 +58,13 @@ def test_strict_is_bit_identical_to_oracle_and_golden(ctx, name):
     assert st.segments == int(gold[name + "_segments"][0])
 
 
+@pytest.mark.parametrize("kernel", list(KERNELS))
 @pytest.mark.parametrize("name", list(CASES))
-def test_fast_build_within_tolerance(ctx, name):
+def test_fast_build_within_tolerance(ctx, name, kernel):
     kind, args, w, aspect, spp, ns, depth, seed = CASES[name]
     scene = make_scene(kind, args)
     cfg = rtow.make_config(w, rtow.image_height(w, aspect), spp, ns, depth, seed=seed,
-                           precision=rtow.F64_FAST, kernel=rtow.KERNEL_BRUTE)
+                           precision=rtow.F64_FAST, kernel=KERNELS[kernel])
     img, st = ctx.render(scene, cfg)
     ref = np.load(GOLDEN / "oracle_philox.npz")[name + "_img"]
     assert np.isfinite(img).all()
@@ -76,6 +82,23 @@ def test_fast_build_8bit_agreement_at_64spp(ctx):
     off = np.abs(to8(img, 64) - to8(ref, 64)) > 1
     assert off.mean() <= 1e-3, off.mean()
     assert np.abs(img - ref).mean() / 64 <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["cover_static", "cover_moving", "suzanne"])
+def test_bvh_and_stream_kernels_agree_bitwise(ctx, name):
+    """Conservative culling: walking the BVH must accept exactly the hits streaming does.
+    ~1.5 M segments per case, strict arithmetic, compared bit for bit."""
+    kind, args, _, aspect, _, _, depth, seed = CASES[name]
+    scene = make_scene(kind, args)
+    w = 320
+    h = rtow.image_height(w, aspect)
+    imgs = []
+    for k in (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH):
+        cfg = rtow.make_config(w, h, 8, 2, depth, seed=seed + 100, precision=rtow.F64_STRICT, kernel=k)
+        img, st = ctx.render(scene, cfg)
+        imgs.append((img, st.segments))
+    assert imgs[0][1] == imgs[1][1]
+    assert np.array_equal(imgs[0][0], imgs[1][0])
 
 
 def test_image_does_not_depend_on_the_partition(ctx):

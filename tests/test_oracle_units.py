@@ -39,14 +39,25 @@ def test_mt19937_stream_and_double_mapping():
     assert L.orc_mt_random_double(-1.0, 1.0) == want * 2.0 + -1.0
 
 
-def test_philox_double_is_a_pure_function_of_its_key():
+def test_philox_requests():
+    """A request is one Philox block: pure function of (seed, pixel, sample, request)."""
     L = orc.lib()
-    a = L.orc_philox_double(42, 1000, 7, 3)
-    assert a == L.orc_philox_double(42, 1000, 7, 3)
-    assert 0.0 <= a < 1.0
-    vals = {L.orc_philox_double(42, p, s, d) for p in range(4) for s in range(4) for d in range(6)}
+    a = L.orc_philox_request(42, 1000, 7, 3, 2, 0)
+    assert a == L.orc_philox_request(42, 1000, 7, 3, 2, 0) and 0.0 <= a < 1.0
+    vals = {L.orc_philox_request(42, p, s, r, 2, k)
+            for p in range(4) for s in range(4) for r in range(3) for k in range(2)}
     assert len(vals) == 96
-    assert L.orc_philox_double(43, 1000, 7, 3) != a
+    assert L.orc_philox_request(43, 1000, 7, 3, 2, 0) != a
+    # the words of the block, by hand: counter (request, sample, pixel, 0), key = seed
+    out = (C.c_uint32 * 4)()
+    L.orc_philox4x32_10((C.c_uint32 * 4)(3, 7, 1000, 0), (C.c_uint32 * 2)(42, 0), out)
+    w = list(out)
+    assert L.orc_philox_request(42, 1000, 7, 3, 2, 0) == (w[0] + w[1] * 2.0**32) / 2.0**64
+    assert L.orc_philox_request(42, 1000, 7, 3, 2, 1) == (w[2] + w[3] * 2.0**32) / 2.0**64
+    # three doubles: 42 bits each (word k + 10 bits of word 3)
+    for k in range(3):
+        want = (w[k] + ((w[3] >> (10 * k)) & 1023) * 2.0**32) / 2.0**42
+        assert L.orc_philox_request(42, 1000, 7, 3, 3, k) == want and want < 1.0
 
 
 def test_sphere_hit_cases():
