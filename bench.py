@@ -47,6 +47,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_VALU_PEAK_TF = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 BYTES_PER_SPHERE = 32    # cx cy cz r^2 as f64 (16 B in f32, doubled for f64)
 FLOPS_PER_SPHERE_TEST = 23  # to the discriminant reject (src/common-model.cpp:70-75)
+BYTES_PER_NODE = 32      # f32 box + skip link + leaf word
+FLOPS_PER_BOX_TEST = 17  # 6 fma-slabs + min/max network
 
 
 def parse():
@@ -179,8 +181,21 @@ def main():
         value = samples / (elapsed / a.steps) / 1e6
         # dominant kernel on THIS rank (rank 0): algorithmic bytes of its launch / its duration
         seg0 = float(st0.segments)
-        alg_bytes = math.ceil(seg0 / 64) * n_prims * BYTES_PER_SPHERE + len(rows) * W * 24
-        alg_flops = seg0 * n_prims * FLOPS_PER_SPHERE_TEST
+        fb_bytes = len(rows) * W * 24
+        if st0.kernel_used == rtow.KERNEL_BRUTE:
+            # streaming model: every wave of 64 segments streams the whole primitive array once
+            alg_bytes = math.ceil(seg0 / 64) * n_prims * BYTES_PER_SPHERE + fb_bytes
+            alg_flops = seg0 * n_prims * FLOPS_PER_SPHERE_TEST
+            model = "ceil(segments/64)*N_prim*32B + rows*W*24B (SURVEY.md §8d, f64 records)"
+            fmodel = "segments*N_prim*23 flop (sphere test to the discriminant reject)"
+        else:
+            # BVH model ('the unit becomes nodes+prims visited per segment'), from the
+            # kernel's own counters: every lane reads a 32 B node per box test and a 32 B record
+            # (+4 B id) per primitive test
+            alg_bytes = int(st0.node_tests) * BYTES_PER_NODE + int(st0.prim_tests) * (BYTES_PER_SPHERE + 4) + fb_bytes
+            alg_flops = int(st0.node_tests) * FLOPS_PER_BOX_TEST + int(st0.prim_tests) * FLOPS_PER_SPHERE_TEST
+            model = "node_tests*32B + prim_tests*36B + rows*W*24B (per-lane reads of the LDS scene image)"
+            fmodel = "node_tests*17 flop (f32 slab) + prim_tests*23 flop (f64 sphere test)"
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         prof = ROOT / "profiles" / "r01_hbm_traffic.json"
@@ -204,8 +219,11 @@ def main():
                                    ("configs[2]" if spp == 500 else "custom"),
                 "spp_effective": spp_eff, "samples_per_item": spp // nstreams, "nstreams": nstreams,
                 "seed": SEED, "precision": a.precision,
-                "kernel": {1: "stream(brute-force, scalar-load broadcast)", 2: "bvh"}[st0.kernel_used],
+                "kernel": {1: "stream (every lane tests every primitive, scalar-load broadcast)",
+                           2: "bvh (per-lane threaded walk of the LDS scene image)"}[st0.kernel_used],
                 "segments_per_sample": round(segments / samples, 4),
+                "node_tests_per_segment": round(st0.node_tests / max(seg0, 1), 3),
+                "prim_tests_per_segment": round(st0.prim_tests / max(seg0, 1), 3),
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -213,13 +231,13 @@ def main():
                 "kernel": "rtow_trace_" + a.precision, "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "model": "ceil(segments/64)*N_prim*32B + rows*W*24B (SURVEY.md §8d, f64 records)",
+                "model": model,
             },
             "roofline_valu": {
                 "bound": "valu_f64", "achieved": round(alg_flops / (kernel_ms * 1e-3) / 1e12, 3),
                 "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(alg_flops / (kernel_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TF, 5),
-                "model": "segments*N_prim*23 flop (sphere test to the discriminant reject)",
+                "model": fmodel,
             },
         }
         if not a.no_cpu_baseline and world == 1:

@@ -68,6 +68,32 @@ struct DevBuf {
   }
 };
 
+// magic/shift for fastdiv(): libdivide's branch-free u32 scheme
+// q = (((n - t) >> 1) + t) >> shift with t = mulhi(n, magic)
+rtow::FastDiv make_fastdiv(uint32_t d) {
+  rtow::FastDiv f{0u, 0u};
+  if (d <= 1) {  // identity: flagged with shift = 255
+    f.shift = 255u;
+    return f;
+  }
+  uint32_t fl = 31u - (uint32_t)__builtin_clz(d);
+  if ((d & (d - 1)) == 0) {  // power of two: t = 0 would give n>>1>>(fl-1)
+    f.magic = 0u;
+    f.shift = fl - 1u;
+    return f;
+  }
+  const uint64_t two = (uint64_t)1 << (32 + fl);
+  uint64_t m = two / d;
+  const uint64_t rem = two - m * d;
+  // round up, doubled (the 33-bit magic's top bit is implicit in the (n-t)>>1 + t step)
+  m = m * 2;
+  const uint64_t twice_rem = rem * 2;
+  if (twice_rem >= d || twice_rem < rem) m += 1;
+  f.magic = (uint32_t)(m + 1);
+  f.shift = fl;
+  return f;
+}
+
 template <class T>
 int upload(DevBuf &b, const std::vector<T> &v) {
   size_t n = v.size() * sizeof(T);
@@ -353,7 +379,12 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   // a handful of primitives is cheaper to stream than to walk
   if (kernel == RTOW_KERNEL_AUTO) kernel = c->n_prims > 16 ? RTOW_KERNEL_BVH : RTOW_KERNEL_BRUTE;
   const bool strict = cfg->precision == RTOW_F64_STRICT;
-  const int block = kernel == RTOW_KERNEL_BVH ? kBvhBlock : kBlock;
+  int block = kernel == RTOW_KERNEL_BVH ? kBvhBlock : kBlock;
+  if (kernel == RTOW_KERNEL_BVH)
+    if (const char *e = std::getenv("RTOW_BVH_BLOCK")) {  // experiment knob
+      const int b = std::atoi(e);
+      if (b == 256 || b == 512 || b == 1024) block = b;
+    }
   // the scene image goes to LDS when one copy per workgroup fits (160 KiB per CU)
   const unsigned lds_bytes = (kernel == RTOW_KERNEL_BVH && c->blob_bytes <= kLdsLimit) ? c->blob_bytes : 0u;
 
@@ -377,6 +408,10 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
                  : rtow::trace_occupancy_fast(kernel, block, lds_bytes);
     if (occ <= 0) return fail(RTOW_EHIP, "occupancy query failed (kernel %d, %u B of LDS)", kernel, lds_bytes);
     if (occ > 8) occ = 8;
+    if (const char *e = std::getenv("RTOW_BLOCKS_PER_CU")) {  // experiment knob
+      const int b = std::atoi(e);
+      if (b >= 1 && b <= 16) occ = b;
+    }
   }
   long long grid = (long long)c->num_cus * occ;
   const long long need_blocks = (long long)((n_items + block - 1) / block);
@@ -407,6 +442,9 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.seed_hi = (uint32_t)(cfg->seed >> 32);
   P.n_items = (uint32_t)n_items;
   P.n_lanes = (uint32_t)n_lanes;
+  P.div_npix = make_fastdiv((uint32_t)npix);
+  P.div_w = make_fastdiv((uint32_t)cfg->image_width);
+  P.div_tile = make_fastdiv((uint32_t)cfg->tile_rows);
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
   P.counters = (unsigned long long *)c->counters.p;

@@ -50,6 +50,10 @@ struct DevScene {
   int32_t n_nodes;
 };
 
+struct FastDiv {  // unsigned division by a per-launch constant (see fastdiv() in the kernel)
+  uint32_t magic, shift;
+};
+
 struct TraceParams {
   DevScene sc;
   DevCamera cam;
@@ -62,6 +66,7 @@ struct TraceParams {
   uint32_t seed_lo, seed_hi;
   uint32_t n_items;        // local_rows * W * nstreams
   uint32_t n_lanes;        // grid * block (stride of the path stack)
+  FastDiv div_npix, div_w, div_tile;  // item -> (stream, row, column, strip)
   double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests

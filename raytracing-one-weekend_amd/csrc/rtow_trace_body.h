@@ -170,18 +170,30 @@ struct Closest {
 
 // sphere_hit_helper up to the accepted root (src/common-model.cpp:70-81);
 // the hit point and normal are computed once, for the winner only.
-__device__ __forceinline__ void sphere_test(V3 o, V3 d, double a, double cx, double cy, double cz,
-                                            double r2, int id, double tmin, Closest &best) {
+// `inv_a` is 1/a, used only by the fast build (one reciprocal per ray instead of two
+// divisions per candidate hit); the strict build divides like the reference.
+__device__ __forceinline__ void sphere_test(V3 o, V3 d, double a, double inv_a, double cx, double cy,
+                                            double cz, double r2, int id, double tmin, Closest &best) {
   V3 oc = {o.x - cx, o.y - cy, o.z - cz};
   double h = dot(oc, d);
   double c = dot(oc, oc) - r2;
   double disc = h * h - a * c;
   if (disc >= 0.0) {
     double sq = sqrt(disc);
+#ifdef RTOW_FAST_MATH
+    double root = (-h - sq) * inv_a;
+    const double root2 = (-h + sq) * inv_a;
+#else
+    (void)inv_a;
     double root = (-h - sq) / a;
+#endif
     bool ok = true;
     if (root < tmin || root > best.t) {
+#ifdef RTOW_FAST_MATH
+      root = root2;
+#else
       root = (-h + sq) / a;
+#endif
       if (root < tmin || root > best.t) ok = false;
     }
     if (ok) {
@@ -216,12 +228,13 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, 
   best.prim = -1;
   const double tmin = RTOW_TMIN;
   const double a = dot(d, d);
+  const double inv_a = 1.0 / a;
   {
     cdptr g = (cdptr)sc.sph;
     const int n = sc.n_sph;
 #pragma unroll 4
     for (int i = 0; i < n; ++i) {
-      sphere_test(o, d, a, g[4 * i + 0], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], i, tmin, best);
+      sphere_test(o, d, a, inv_a, g[4 * i + 0], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], i, tmin, best);
     }
   }
   {
@@ -234,7 +247,7 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, 
       double cx = g[8 * i + 0] + time * g[8 * i + 3];
       double cy = g[8 * i + 1] + time * g[8 * i + 4];
       double cz = g[8 * i + 2] + time * g[8 * i + 5];
-      sphere_test(o, d, a, cx, cy, cz, g[8 * i + 6], base + i, tmin, best);
+      sphere_test(o, d, a, inv_a, cx, cy, cz, g[8 * i + 6], base + i, tmin, best);
     }
   }
   {
@@ -288,8 +301,8 @@ __device__ __forceinline__ float safe_inv(float d) {
 
 template <bool LDS>
 __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, uint32_t leaf,
-                                          V3 o, V3 d, double a, double time, Closest &best,
-                                          uint32_t &nprim) {
+                                          V3 o, V3 d, double a, double inv_a, double time,
+                                          Closest &best, uint32_t &nprim) {
   const uint32_t first = leaf >> 3, count = leaf & 7u;
   for (uint32_t k = 0; k < count; ++k) {
     const int id = (int)im.u32(sc.off_ids + 4u * (first + k));
@@ -297,14 +310,14 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
     if (id < sc.n_sph) {
       const uint32_t off = sc.off_sph + 32u * (uint32_t)id;
       const double2 p0 = im.d2(off), p1 = im.d2(off + 16u);
-      sphere_test(o, d, a, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+      sphere_test(o, d, a, inv_a, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
     } else if (id < sc.n_sph + sc.n_mov) {
       const uint32_t off = sc.off_mov + 64u * (uint32_t)(id - sc.n_sph);
       const double2 p0 = im.d2(off), p1 = im.d2(off + 16u), p2 = im.d2(off + 32u), p3 = im.d2(off + 48u);
       const double cx = p0.x + time * p1.y;
       const double cy = p0.y + time * p2.x;
       const double cz = p1.x + time * p2.y;
-      sphere_test(o, d, a, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
+      sphere_test(o, d, a, inv_a, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
     } else {
       const uint32_t off = sc.off_tri + 96u * (uint32_t)(id - sc.n_sph - sc.n_mov);
       const double2 q0 = im.d2(off), q1 = im.d2(off + 16u), q2 = im.d2(off + 32u),
@@ -323,6 +336,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   best.t = __builtin_huge_val();
   best.prim = -1;
   const double a = dot(d, d);
+  const double inv_a = 1.0 / a;
   // f32 copy of the ray for the (conservative) box tests
   const float ix = safe_inv((float)d.x), iy = safe_inv((float)d.y), iz = safe_inv((float)d.z);
   const float oix = (float)o.x * ix, oiy = (float)o.y * iy, oiz = (float)o.z * iz;
@@ -354,8 +368,8 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
     const bool any_walking = __any(node != END);
     if (__any(q1 != 0u) || !any_walking) {
       // leaf phase: every lane tests the primitives of the leaves it queued
-      if (q0 != 0u) leaf_test(im, sc, q0, o, d, a, time, best, nprim);
-      if (q1 != 0u) leaf_test(im, sc, q1, o, d, a, time, best, nprim);
+      if (q0 != 0u) leaf_test(im, sc, q0, o, d, a, inv_a, time, best, nprim);
+      if (q1 != 0u) leaf_test(im, sc, q1, o, d, a, inv_a, time, best, nprim);
       q0 = 0u;
       q1 = 0u;
       // shrink the f32 interval (rounded up: never below the f64 value)
@@ -367,13 +381,22 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
 }
 
 // --------------------------------------------------------------- the kernel ---
+// n / d for a divisor fixed per launch: q = (((n - t) >> 1) + t) >> shift, t = mulhi(n, magic)
+// (round-up method, exact for every 32-bit n; magic/shift come from the host).
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDiv f) {
+  const uint32_t t = __umulhi(n, f.magic);
+  return f.shift == 255u ? n : (((n - t) >> 1) + t) >> f.shift;  // shift 255: divisor 1
+}
+
+constexpr uint32_t kItemBatch = 64;  // work items fetched per global atomic (per wave)
+
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
 // KERNEL: 1 = STREAM, 2 = BVH;  LDS: scene image staged in LDS (BVH only)
 template <int KERNEL, bool LDS>
-__global__ void __launch_bounds__(KERNEL == 2 ? 512 : 256)
+__global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
     RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const TraceParams P) {
   const DevScene &sc = P.sc;
   const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
@@ -406,6 +429,7 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 512 : 256)
   int nb = 0;                 // bounces recorded on the path stack
   Rng g = {0, 0, 0};
   uint32_t nseg = 0, nnode = 0, nprim = 0;
+  uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: this wave's batch of work items
 
   for (;;) {
     // ---- item bookkeeping ---------------------------------------------------
@@ -421,22 +445,38 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 512 : 256)
     }
     const unsigned long long need_mask = __ballot(need_item);
     if (need_mask != 0ull) {
-      const int leader = __ffsll((long long)need_mask) - 1;
-      unsigned long long base = 0ull;
-      if ((int)lane == leader) base = atomicAdd(&P.counters[0], (unsigned long long)__popcll(need_mask));
-      base = __shfl(base, leader);
+      // Wave-local pool [pool_next, pool_end): one global atomic buys kItemBatch items,
+      // which the lanes then take by ballot rank with no further traffic (a single hot
+      // counter word saturates near 90 dequeues/us on this chip — one atomic per wave
+      // trip was the bottleneck).  All of this is wave-uniform except `mine`.
+      const uint32_t want = (uint32_t)__popcll(need_mask);
+      const uint32_t avail = pool_end - pool_next;
+      const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
+      unsigned long long mine = (unsigned long long)pool_next + rank;
+      if (want > avail) {
+        const int leader = __ffsll((long long)need_mask) - 1;
+        unsigned long long base = 0ull;
+        if ((int)lane == leader) base = atomicAdd(&P.counters[0], (unsigned long long)kItemBatch);
+        base = __shfl(base, leader);
+        if (rank >= avail) mine = base + (rank - avail);
+        const unsigned long long nn = base + (want - avail), ne = base + kItemBatch;
+        const unsigned long long cap = (unsigned long long)P.n_items;
+        pool_next = (uint32_t)(nn < cap ? nn : cap);
+        pool_end = (uint32_t)(ne < cap ? ne : cap);
+      } else {
+        pool_next += want;
+      }
       if (need_item) {
-        const unsigned long long mine = base + (unsigned long long)__popcll(need_mask & ((1ull << lane) - 1ull));
         if (mine >= (unsigned long long)P.n_items) {
           done = true;
         } else {
           item = (uint32_t)mine;
-          const uint32_t k = item / npix_local;     // stream
-          const uint32_t lp = item - k * npix_local; // local pixel
-          const uint32_t lr = lp / (uint32_t)P.W;
+          const uint32_t k = fastdiv(item, P.div_npix);  // stream
+          const uint32_t lp = item - k * npix_local;     // local pixel
+          const uint32_t lr = fastdiv(lp, P.div_w);
           j = lp - lr * (uint32_t)P.W;
           // local row -> global row: this rank's q-th strip is global strip q*nranks+rank
-          const uint32_t q = lr / (uint32_t)P.tile_rows;
+          const uint32_t q = fastdiv(lr, P.div_tile);
           const uint32_t rr = lr - q * (uint32_t)P.tile_rows;
           gi = (q * (uint32_t)P.nranks + (uint32_t)P.rank) * (uint32_t)P.tile_rows + rr;
           g.pixel = gi * (uint32_t)P.W + j;
@@ -627,21 +667,39 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
   return (int)hipGetLastError();
 }
 
+// Workgroups per CU that stay resident: min over the register file (512 VGPRs per
+// SIMD lane, allocated in granules of 8), the 32-wave CU limit and the 160 KiB of LDS.
+// (The runtime's occupancy query ignores LDS above 64 KiB per CU on this stack; a grid
+// that turns out larger than resident only queues the surplus workgroups, which then
+// find the work queue empty — there is no inter-workgroup dependency.)
 int RTOW_CAT(trace_occupancy_, RTOW_SUFFIX)(int kernel, int block, unsigned lds_bytes) {
-  int nb = 0;
-  hipError_t e;
+  const void *fn;
   if (kernel == 2 && lds_bytes > 0) {
     auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true>;
+    fn = reinterpret_cast<const void *>(k);
     if (lds_bytes > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, block, lds_bytes);
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   } else if (kernel == 2) {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, false>, block, 0);
+    auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, false>;
+    fn = reinterpret_cast<const void *>(k);
   } else {
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<1, false>, block, 0);
+    auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<1, false>;
+    fn = reinterpret_cast<const void *>(k);
   }
-  if (e != hipSuccess) return -1;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return -1;
+  const int regs = fa.numRegs > 0 ? fa.numRegs : 128;
+  const int alloc = ((regs + 7) / 8) * 8;
+  int waves_per_simd = 512 / alloc;
+  if (waves_per_simd > 8) waves_per_simd = 8;
+  if (waves_per_simd < 1) waves_per_simd = 1;
+  const int waves_per_block = block / 64;
+  int nb = (waves_per_simd * 4) / waves_per_block;
+  if (lds_bytes > 0) {
+    const int by_lds = (int)((160u * 1024u) / lds_bytes);
+    if (by_lds < nb) nb = by_lds;
+  }
+  if (nb < 1) nb = 1;
   return nb;
 }
 
