@@ -40,6 +40,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import rtow  # noqa: E402
+import tiles  # noqa: E402
 
 W, ASPECT, DEPTH, SEED = 1200, 1.5, 50, 1
 SAMPLES_PER_ITEM = 10
@@ -65,15 +66,27 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(scene, height, seconds):
     """Time the oracle (kind 'port') on this host: same scene/resolution, reduced spp."""
     sys.path.insert(0, str(ROOT / "tests"))
     import orc
 
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     cal = rtow.make_config(W, height, 1, 1, DEPTH, seed=SEED)
     t0 = time.perf_counter()
     orc.render(scene, cal, orc.RNG_PHILOX, nthreads=cores)
@@ -121,26 +134,15 @@ def main():
     ctx.upload(scene)  # scene resident in HBM before the timed region
 
     rows = rtow.local_rows(cfg)
-    max_rows = max(len(rtow.local_rows(rtow.make_config(W, H, spp, nstreams, DEPTH, rank=r,
-                                                        nranks=world, tile_rows=tile_rows)))
-                   for r in range(world))
-    local = torch.zeros((max_rows, W, 3), dtype=torch.float64, device=dev)
-    image = torch.zeros((H, W, 3), dtype=torch.float64, device=dev) if rank == 0 else None
-    gathered = ([torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None)
-    row_index = None
-    if rank == 0 and world > 1:
-        row_index = [torch.tensor(rtow.local_rows(rtow.make_config(W, H, spp, nstreams, DEPTH, rank=r,
-                                                                   nranks=world, tile_rows=tile_rows)),
-                                  device=dev, dtype=torch.long) for r in range(world)]
+    sg = tiles.StripGather(H, W, tile_rows, rank, world, dev)
+    assert sg.rows == rows
+    local = sg.local
     stream = torch.cuda.current_stream(dev)
 
     def step(want_stats=False):
         st = ctx.render_device(cfg, local.data_ptr(), stream.cuda_stream, want_stats)
         if world > 1:
-            dist.gather(local, gathered, dst=0)  # the one collective: framebuffer strips -> rank 0
-            if rank == 0:
-                for r in range(world):
-                    image.index_copy_(0, row_index[r], gathered[r][: row_index[r].numel()])
+            sg.gather()  # the one collective: framebuffer strips -> rank 0 (RCCL gather)
         return st
 
     def fence():

@@ -57,7 +57,7 @@ extern "C" {
 /* closest-hit strategies */
 #define RTOW_KERNEL_AUTO 0
 #define RTOW_KERNEL_BRUTE 1 /* every ray tests every primitive (wave-uniform stream)   */
-#define RTOW_KERNEL_BVH 2   /* per-lane stack traversal of the flattened BVH            */
+#define RTOW_KERNEL_BVH 2   /* every lane walks a threaded (stackless) BVH in LDS       */
 
 /* Camera state: exactly the private members of the reference Camera after its
  * constructor ran (src/common-model.h:104-112, src/common-model.cpp:136-154). */
@@ -181,6 +181,11 @@ int rtow_render_device(rtow_ctx *ctx, const rtow_config_t *cfg, void *d_rgb_sums
  * ring: `*kernel_ms_sum` = total trace-kernel milliseconds, `*launches` = how
  * many launches that covers (the ring keeps the first 256 per collect). */
 int rtow_profile_collect(rtow_ctx *ctx, double *kernel_ms_sum, int32_t *launches);
+
+/* Diagnostic only: copies the 16 device counters of the last launch (see
+ * csrc/rtow_trace_body.h; [8..12] are wave-cycle sums per region when the
+ * RTOW_STAMPS diagnostic kernel ran). */
+int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out16);
 
 /* Convenience: upload + render + copy this rank's rows to host memory. */
 int rtow_render(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,

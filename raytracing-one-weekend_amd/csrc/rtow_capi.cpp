@@ -422,7 +422,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   const size_t depth_slots = (size_t)(cfg->max_child_rays > 0 ? cfg->max_child_rays : 1);
   if ((rc = c->partials.ensure((size_t)n_items * 3 * sizeof(double))) ||
       (rc = c->stack.ensure(depth_slots * (size_t)n_lanes * sizeof(uint32_t))) ||
-      (rc = c->counters.ensure(4 * sizeof(unsigned long long))))
+      (rc = c->counters.ensure(16 * sizeof(unsigned long long))))
     return rc;
 
   rtow::TraceParams P;
@@ -450,11 +450,13 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.counters = (unsigned long long *)c->counters.p;
 
   if (stats) HIPCHK(hipEventRecord(c->call_ev[0], st));
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(unsigned long long), st));
   const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
   if (slot >= 0) HIPCHK(hipEventRecord(c->ev[slot][0], st));
-  int lrc = strict ? rtow::launch_trace_strict(P, kernel, (int)grid, block, lds_bytes, st)
-                   : rtow::launch_trace_fast(P, kernel, (int)grid, block, lds_bytes, st);
+  int launch_kernel = kernel;
+  if (kernel == RTOW_KERNEL_BVH && lds_bytes > 0 && std::getenv("RTOW_STAMPS")) launch_kernel = 3;  // diagnostic
+  int lrc = strict ? rtow::launch_trace_strict(P, launch_kernel, (int)grid, block, lds_bytes, st)
+                   : rtow::launch_trace_fast(P, launch_kernel, (int)grid, block, lds_bytes, st);
   if (lrc != 0) return fail(RTOW_EHIP, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   if (slot >= 0) {
     HIPCHK(hipEventRecord(c->ev[slot][1], st));
@@ -490,6 +492,17 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
       stats->node_tests = c->h_counters[3];
     }
   }
+  return RTOW_OK;
+}
+
+// Diagnostic: the 16 device counters of the last launch (work queue, segments, prim
+// tests, node tests, ... region cycle sums of the RTOW_STAMPS build at [8..12]).
+int rtow_debug_counters(rtow_ctx *c, unsigned long long *out16) {
+  if (!c || !out16) return fail(RTOW_EINVAL, "NULL argument");
+  if (!c->counters.p) return fail(RTOW_ENOSCENE, "no launch yet");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out16, c->counters.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RTOW_OK;
 }
 

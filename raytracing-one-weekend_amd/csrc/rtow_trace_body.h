@@ -367,14 +367,14 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
     }
     const bool any_walking = __any(node != END);
     if (__any(q1 != 0u) || !any_walking) {
-      // leaf phase: every lane tests the primitives of the leaves it queued
+      // leaf phase: every lane tests the primitives of the OLDEST leaf it queued (most
+      // lanes hold one; only the lanes whose queue filled hold two, and theirs moves up)
       if (q0 != 0u) leaf_test(im, sc, q0, o, d, a, inv_a, time, best, nprim);
-      if (q1 != 0u) leaf_test(im, sc, q1, o, d, a, inv_a, time, best, nprim);
-      q0 = 0u;
+      q0 = q1;
       q1 = 0u;
       // shrink the f32 interval (rounded up: never below the f64 value)
       tmax32 = __double2float_ru(best.t);
-      if (!any_walking) break;
+      if (!any_walking && !__any(q0 != 0u)) break;
     }
   }
   return best;
@@ -394,8 +394,36 @@ __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// Diagnostic region stamps (STAMPS build only, never in a timed run): wave cycles per
+// region of the main loop, accumulated in scalar registers and added to
+// counters[8 + region] once per wave.  Shares, not absolute times (each stamp drains
+// the wave's outstanding memory operations).
+enum { RG_FETCH = 0, RG_REGEN, RG_WALK, RG_SHADE, RG_OTHER, RG_COUNT };
+template <bool ON>
+struct Stamps {
+  unsigned long long t[RG_COUNT] = {0, 0, 0, 0, 0};
+  unsigned long long last = 0;
+  __device__ __forceinline__ void start() {
+    if constexpr (ON) last = now();
+  }
+  __device__ __forceinline__ void mark(int region) {
+    if constexpr (ON) {
+      const unsigned long long n = now();
+      t[region] += n - last;
+      last = n;
+    }
+  }
+  static __device__ __forceinline__ unsigned long long now() {
+    unsigned long long v;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return v;
+  }
+};
+
 // KERNEL: 1 = STREAM, 2 = BVH;  LDS: scene image staged in LDS (BVH only)
-template <int KERNEL, bool LDS>
+template <int KERNEL, bool LDS, bool STAMPS = false>
 __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
     RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const TraceParams P) {
   const DevScene &sc = P.sc;
@@ -430,6 +458,8 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
   Rng g = {0, 0, 0};
   uint32_t nseg = 0, nnode = 0, nprim = 0;
   uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: this wave's batch of work items
+  Stamps<STAMPS> stamps;
+  stamps.start();
 
   for (;;) {
     // ---- item bookkeeping ---------------------------------------------------
@@ -487,6 +517,7 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
       }
     }
     if (__ballot(!done) == 0ull) break;
+    stamps.mark(RG_FETCH);
 
     // (a lane whose fresh item has no samples — spt == 0 — goes straight back for the next one)
     const bool live = !done && !(need_sample && s_left <= 0);
@@ -521,6 +552,7 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
       need_sample = false;
     }
 
+    stamps.mark(RG_REGEN);
     // ---- one ray segment: closest hit --------------------------------------------
     Closest best;
     best.t = 0.0;
@@ -532,6 +564,7 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
       if (live) best = closest_hit_stream(sc, ro, rd, rtime);
     }
 
+    stamps.mark(RG_WALK);
     if (live) {
       ++nseg;
       if (best.prim >= 0) {
@@ -625,6 +658,11 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
         ++g.sample;
       }
     }
+    stamps.mark(RG_SHADE);
+  }
+  if constexpr (STAMPS) {
+    if (lane == 0)
+      for (int r = 0; r < RG_COUNT; ++r) atomicAdd(&P.counters[8 + r], stamps.t[r]);
   }
 
   // stats: one atomic per wave and counter
@@ -649,6 +687,16 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
 int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int grid, int block,
                                          unsigned lds_bytes, void *stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (kernel == 3) {  // diagnostic: BVH + LDS image + region stamps
+    auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true, true>;
+    if (lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, st, p);
+    return (int)hipGetLastError();
+  }
   if (kernel == 2) {
     if (lds_bytes > 0) {
       auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true>;

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Region shares of the BVH trace kernel (diagnostic RTOW_STAMPS build)."""
+import ctypes as C, os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "raytracing-one-weekend_amd"))
+os.environ["RTOW_STAMPS"] = "1"
+import rtow
+which = sys.argv[1] if len(sys.argv) > 1 else "cover"
+if which == "suzanne":
+    scene = rtow.HostScene.obj(ROOT / "tests/golden/suzanne.obj")
+    cfg = rtow.make_config(1920, 1080, 16, 2, 20, seed=1, precision=rtow.F64_FAST, kernel=rtow.KERNEL_BVH)
+else:
+    scene = rtow.HostScene.cover(11, 1.5, which == "moving")
+    cfg = rtow.make_config(1200, 800, 100, 10, 50, seed=1, precision=rtow.F64_FAST, kernel=rtow.KERNEL_BVH)
+ctx = rtow.Context(0)
+img, st = ctx.render(scene, cfg)
+out = (C.c_ulonglong * 16)()
+L = rtow.lib(); L.rtow_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+rtow.check(L.rtow_debug_counters(ctx._h, out))
+names = ["fetch", "regen", "walk", "shade", "other"]
+tot = sum(out[8:13]) or 1
+print(which, "kernel_ms(with stamps)", round(st.kernel_ms, 3), "Msamples/s", round(st.samples / st.kernel_ms / 1e3, 1),
+      "segments", st.segments, "node/seg", round(st.node_tests / st.segments, 2), "prim/seg", round(st.prim_tests / st.segments, 2))
+for i, n in enumerate(names):
+    print(f"{n:6s} {out[8+i]/tot*100:5.1f}%")
