@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--kernel", choices=["auto", "brute", "bvh"], default="auto")
     ap.add_argument("--moving", action="store_true", help="moving-sphere variant of the cover scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = rehearsal of the N>1 path with every rank on cuda:0 (1-GPU box)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -113,11 +115,17 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    rehearsal = a.backend == "gloo"
+    if rehearsal:
+        local_rank = 0  # all ranks share the one GPU; collectives go through host memory
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     H = rtow.image_height(W, ASPECT)
     spp = a.spp or (100 if world == 1 else 500)
@@ -134,14 +142,16 @@ def main():
     ctx.upload(scene)  # scene resident in HBM before the timed region
 
     rows = rtow.local_rows(cfg)
-    sg = tiles.StripGather(H, W, tile_rows, rank, world, dev)
+    sg = tiles.StripGather(H, W, tile_rows, rank, world, torch.device("cpu") if rehearsal else dev)
     assert sg.rows == rows
-    local = sg.local
+    local = torch.zeros_like(sg.local, device=dev) if rehearsal else sg.local
     stream = torch.cuda.current_stream(dev)
 
     def step(want_stats=False):
         st = ctx.render_device(cfg, local.data_ptr(), stream.cuda_stream, want_stats)
         if world > 1:
+            if rehearsal:
+                sg.local.copy_(local)  # gloo has no device gather: stage through the host
             sg.gather()  # the one collective: framebuffer strips -> rank 0 (RCCL gather)
         return st
 
@@ -171,6 +181,8 @@ def main():
     tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
     work = torch.tensor([float(st0.samples), float(st0.segments)], dtype=torch.float64, device=dev)
     if world > 1:
+        if rehearsal:
+            tt, work = tt.cpu(), work.cpu()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(work, op=dist.ReduceOp.SUM)
     elapsed, kernel_ms_max = float(tt[0]), float(tt[1])
@@ -212,7 +224,8 @@ def main():
             "metric": "Msamples/sec (W×H×spp) on cover scene; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "config": {
                 "workload": f"RTOW cover scene ({n_prims} prims, {'moving' if a.moving else 'static'}) "
                             f"{W}x{H}, {spp} spp, {DEPTH} bounces"

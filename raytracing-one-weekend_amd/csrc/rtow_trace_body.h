@@ -266,6 +266,35 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, 
   return best;
 }
 
+// Diagnostic region stamps (STAMPS build only, never in a timed run): wave cycles per
+// region of the main loop, accumulated in scalar registers and added to
+// counters[8 + region] once per wave.  Shares, not absolute times (each stamp drains
+// the wave's outstanding memory operations).
+enum { RG_FETCH = 0, RG_REGEN, RG_WALK, RG_SHADE, RG_LEAF, RG_COUNT };
+template <bool ON>
+struct Stamps {
+  unsigned long long t[RG_COUNT] = {0, 0, 0, 0, 0};
+  unsigned long long last = 0;
+  unsigned long long iters = 0, trips = 0, phases = 0;  // wave-level loop counts
+  __device__ __forceinline__ void start() {
+    if constexpr (ON) last = now();
+  }
+  __device__ __forceinline__ void mark(int region) {
+    if constexpr (ON) {
+      const unsigned long long n = now();
+      t[region] += n - last;
+      last = n;
+    }
+  }
+  static __device__ __forceinline__ unsigned long long now() {
+    unsigned long long v;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return v;
+  }
+};
+
 // ---------------------------------------------------------- closest hit: BVH ---
 extern __shared__ __align__(16) unsigned char rtow_lds[];
 
@@ -328,10 +357,10 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
   }
 }
 
-template <bool LDS>
+template <bool LDS, bool ST>
 __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const DevScene &sc, V3 o,
                                                    V3 d, double time, bool active, uint32_t &nnode,
-                                                   uint32_t &nprim) {
+                                                   uint32_t &nprim, Stamps<ST> &stamps) {
   Closest best;
   best.t = __builtin_huge_val();
   best.prim = -1;
@@ -347,6 +376,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
   uint32_t q0 = 0u, q1 = 0u;  // queued leaves (0 = empty)
   for (;;) {
+    if constexpr (ST) stamps.iters += 1;
     if (node != END) {
       const float4 r0 = im.f4(node * 32u), r1 = im.f4(node * 32u + 16u);
       ++nnode;
@@ -367,6 +397,8 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
     }
     const bool any_walking = __any(node != END);
     if (__any(q1 != 0u) || !any_walking) {
+      stamps.mark(RG_WALK);
+      if constexpr (ST) stamps.phases += 1;
       // leaf phase: every lane tests the primitives of the OLDEST leaf it queued (most
       // lanes hold one; only the lanes whose queue filled hold two, and theirs moves up)
       if (q0 != 0u) leaf_test(im, sc, q0, o, d, a, inv_a, time, best, nprim);
@@ -374,6 +406,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
       q1 = 0u;
       // shrink the f32 interval (rounded up: never below the f64 value)
       tmax32 = __double2float_ru(best.t);
+      stamps.mark(RG_LEAF);
       if (!any_walking && !__any(q0 != 0u)) break;
     }
   }
@@ -393,34 +426,6 @@ constexpr uint32_t kItemBatch = 64;  // work items fetched per global atomic (pe
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
-
-// Diagnostic region stamps (STAMPS build only, never in a timed run): wave cycles per
-// region of the main loop, accumulated in scalar registers and added to
-// counters[8 + region] once per wave.  Shares, not absolute times (each stamp drains
-// the wave's outstanding memory operations).
-enum { RG_FETCH = 0, RG_REGEN, RG_WALK, RG_SHADE, RG_OTHER, RG_COUNT };
-template <bool ON>
-struct Stamps {
-  unsigned long long t[RG_COUNT] = {0, 0, 0, 0, 0};
-  unsigned long long last = 0;
-  __device__ __forceinline__ void start() {
-    if constexpr (ON) last = now();
-  }
-  __device__ __forceinline__ void mark(int region) {
-    if constexpr (ON) {
-      const unsigned long long n = now();
-      t[region] += n - last;
-      last = n;
-    }
-  }
-  static __device__ __forceinline__ unsigned long long now() {
-    unsigned long long v;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return v;
-  }
-};
 
 // KERNEL: 1 = STREAM, 2 = BVH;  LDS: scene image staged in LDS (BVH only)
 template <int KERNEL, bool LDS, bool STAMPS = false>
@@ -553,13 +558,14 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
     }
 
     stamps.mark(RG_REGEN);
+    if constexpr (STAMPS) stamps.trips += 1;
     // ---- one ray segment: closest hit --------------------------------------------
     Closest best;
     best.t = 0.0;
     best.prim = -1;
     if constexpr (KERNEL == 2) {
       // the walk uses wave votes, so every lane of the wave enters it
-      best = closest_hit_bvh<LDS>(im, sc, ro, rd, rtime, live, nnode, nprim);
+      best = closest_hit_bvh<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
     } else {
       if (live) best = closest_hit_stream(sc, ro, rd, rtime);
     }
@@ -662,7 +668,12 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
   }
   if constexpr (STAMPS) {
     if (lane == 0)
+    {
       for (int r = 0; r < RG_COUNT; ++r) atomicAdd(&P.counters[8 + r], stamps.t[r]);
+      atomicAdd(&P.counters[13], stamps.iters);
+      atomicAdd(&P.counters[14], stamps.trips);
+      atomicAdd(&P.counters[15], stamps.phases);
+    }
   }
 
   // stats: one atomic per wave and counter

@@ -18,9 +18,12 @@ img, st = ctx.render(scene, cfg)
 out = (C.c_ulonglong * 16)()
 L = rtow.lib(); L.rtow_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 rtow.check(L.rtow_debug_counters(ctx._h, out))
-names = ["fetch", "regen", "walk", "shade", "other"]
+names = ["fetch", "regen", "walk-steps", "shade", "walk-leaves"]
 tot = sum(out[8:13]) or 1
 print(which, "kernel_ms(with stamps)", round(st.kernel_ms, 3), "Msamples/s", round(st.samples / st.kernel_ms / 1e3, 1),
       "segments", st.segments, "node/seg", round(st.node_tests / st.segments, 2), "prim/seg", round(st.prim_tests / st.segments, 2))
 for i, n in enumerate(names):
     print(f"{n:6s} {out[8+i]/tot*100:5.1f}%")
+iters, trips, phases = out[13], out[14], out[15]
+print(f"wave trips {trips}, step-loop iterations per trip {iters/max(trips,1):.1f}, leaf phases per trip {phases/max(trips,1):.2f}, "
+      f"lane-segments per trip {st.segments/max(trips,1):.1f} of 64")
