@@ -17,11 +17,11 @@
 //               libstdc++'s uniform_real_distribution mapping
 //               (src/random-utils.cpp:6-13): two 32-bit draws per double.
 //   PhiloxDraw— the device path's counter-based stream.  Random numbers are drawn
-//               in REQUESTS (the draw sites of the reference: pixel jitter = 2
-//               doubles, one disk candidate = 2, shutter time = 1, one unit-ball
-//               candidate = 3, the dielectric coin = 1); request r of sample s of
-//               pixel p is ONE Philox4x32-10 block, counter (r, s, p, 0), key =
-//               seed — a pure function of (seed, p, s, r).
+//               in REQUESTS, one Philox4x32-7 block each, counter (r, s, p, 0), key =
+//               seed, a pure function of (seed, pixel p, sample s, request r):
+//               pixel jitter + shutter time share one block, every disk candidate
+//               and every unit-ball candidate takes one, and the dielectric coin
+//               rides in the spare word of the bounce's first unit-ball candidate.
 
 #include "rtow_oracle.h"
 
@@ -133,14 +133,22 @@ struct MtGlobal {
     return canonical_from_words(w0, w1);
   }
   void begin_sample(uint32_t, uint32_t) {}
-  void request(int) {}  // the global stream has no request structure
+  // the global stream has no request structure
+  void request_jitter() {}
+  void request_disk() {}
+  void request_time() {}
+  void request_coin() {}
+  void request_scatter() {}
 };
 
-// Philox4x32-10 (Salmon et al., SC'11), the device path's generator.
-inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+// Philox4x32-R (Salmon et al., SC'11).  The device path uses R = 7, the fastest member
+// of the family that the paper reports as Crush-resistant; R = 10 is kept for the
+// published known-answer vectors.
+constexpr int kPhiloxRounds = 7;
+inline void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds) {
   uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
   uint32_t k0 = key[0], k1 = key[1];
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -160,37 +168,73 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
   out[3] = c3;
 }
 
-// One request = one block.  1 or 2 doubles: words {0,1} and {2,3}, each pair mapped
-// like the reference's doubles (53 significant bits).  3 doubles: 42 bits each —
-// word k plus 10 bits of word 3 — which is exact in a double and never 1.0.
+// One request = one Philox block = four 32-bit words w0..w3:
+//   jitter+time : u = (w0,w1) and v = (w2,w3) mapped like the reference's doubles would
+//                 leave nothing for the shutter time, so this request takes 42 bits per
+//                 value instead: u, v, time = (w_k + 2^32 * bits(10k..10k+9 of w3)) * 2^-42
+//   disk        : y = (w0,w1), x = (w2,w3), each mapped like libstdc++ maps two mt19937 words
+//   scatter     : unit-ball candidate x,y,z = w0,w1,w2 * 2^-32; w3 * 2^-32 is the dielectric
+//                 coin, meaningful only in the FIRST candidate block of a bounce
 struct PhiloxDraw {
   uint64_t seed = 0;
   uint32_t pixel = 0, sample = 0, r = 0;
   uint64_t ndraws = 0;
   double buf[3];
   int have = 0, pos = 0;
+  double stash_time = 0.0;   // third value of the jitter request
+  bool coin_peeked = false;  // the next scatter request re-uses the block the coin came from
   void begin_sample(uint32_t p, uint32_t s) {
     pixel = p;
     sample = s;
     r = 0;
     have = pos = 0;
+    coin_peeked = false;
   }
-  void request(int n) {
-    uint32_t ctr[4] = {r++, sample, pixel, 0u};
+  void block(uint32_t req, uint32_t o[4]) const {
+    uint32_t ctr[4] = {req, sample, pixel, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    philox4x32(ctr, key, o, kPhiloxRounds);
+  }
+  void request_jitter() {
     uint32_t o[4];
-    philox4x32_10(ctr, key, o);
-    if (n <= 2) {
-      buf[0] = canonical_from_words(o[0], o[1]);
-      buf[1] = canonical_from_words(o[2], o[3]);
-    } else {
-      const double s42 = 0x1p-42;
-      buf[0] = ((double)o[0] + (double)(o[3] & 1023u) * 4294967296.0) * s42;
-      buf[1] = ((double)o[1] + (double)((o[3] >> 10) & 1023u) * 4294967296.0) * s42;
-      buf[2] = ((double)o[2] + (double)((o[3] >> 20) & 1023u) * 4294967296.0) * s42;
-    }
-    have = n;
+    block(r++, o);
+    const double s42 = 0x1p-42;
+    buf[0] = ((double)o[0] + (double)(o[3] & 1023u) * 4294967296.0) * s42;
+    buf[1] = ((double)o[1] + (double)((o[3] >> 10) & 1023u) * 4294967296.0) * s42;
+    stash_time = ((double)o[2] + (double)((o[3] >> 20) & 1023u) * 4294967296.0) * s42;
+    have = 2;
     pos = 0;
+  }
+  void request_disk() {
+    uint32_t o[4];
+    block(r++, o);
+    buf[0] = canonical_from_words(o[0], o[1]);
+    buf[1] = canonical_from_words(o[2], o[3]);
+    have = 2;
+    pos = 0;
+  }
+  void request_time() {
+    buf[0] = stash_time;
+    have = 1;
+    pos = 0;
+  }
+  void request_coin() {  // peek at the block the first scatter candidate will use
+    uint32_t o[4];
+    block(r, o);
+    buf[0] = (double)o[3] * 0x1p-32;
+    have = 1;
+    pos = 0;
+    coin_peeked = true;
+  }
+  void request_scatter() {
+    uint32_t o[4];
+    block(r++, o);
+    buf[0] = (double)o[0] * 0x1p-32;
+    buf[1] = (double)o[1] * 0x1p-32;
+    buf[2] = (double)o[2] * 0x1p-32;
+    have = 3;
+    pos = 0;
+    coin_peeked = false;
   }
   double canonical() {
     if (pos >= have) std::abort();  // a draw outside a request: oracle bug
@@ -217,7 +261,7 @@ inline V3 random_vec3(R &rng, double lo = 0.0, double hi = 1.0) {
 template <class R>
 inline V3 random_in_unit_sphere(R &rng) {
   for (;;) {
-    rng.request(3);
+    rng.request_scatter();
     V3 v = random_vec3(rng);
     if (dot(v, v) >= 1) continue;
     return v;
@@ -233,7 +277,7 @@ inline V3 random_unit_vector(R &rng) {
 template <class R>
 inline V3 random_in_unit_disk(R &rng) {
   for (;;) {
-    rng.request(2);
+    rng.request_disk();
     double py = random_double(rng, -1, 1);
     double px = random_double(rng, -1, 1);
     V3 p{px, py, 0};
@@ -544,7 +588,7 @@ bool scatter_dielectric(const Material &m, const Ray &rin, const Hit &rec, R &rn
   double ratio = rec.front ? (1.0 / m.ir) : m.ir;
   bool cannot_refract = ratio * sin_theta > 1.0;
   V3 direction;
-  if (!cannot_refract) rng.request(1);  // the coin is drawn only if refraction is possible
+  if (!cannot_refract) rng.request_coin();  // the coin is drawn only if refraction is possible
   if (cannot_refract || reflectance(cos_theta, ratio) > random_double(rng))
     direction = reflect(unit, rec.normal);
   else
@@ -603,7 +647,7 @@ Ray camera_get_ray(const rtow_camera_t &c, double s, double t, R &rng) {
   V3 offset = load3(c.u) * rd.x + load3(c.v) * rd.y;
   V3 from = load3(c.origin) + offset;
   V3 direction = load3(c.lower_left_corner) + s * load3(c.horizontal) + t * load3(c.vertical) - from;
-  rng.request(1);
+  rng.request_time();
   double when = random_double(rng, c.t0, c.t1);
   return Ray{from, direction, when};
 }
@@ -755,7 +799,7 @@ template <class R>
 inline V3 trace_sample(const World &w, const Bvh &bvh, const rtow_config_t &cfg, int i, int j,
                        R &rng, Counters &cnt) {
   int from_top_i = cfg.image_height - i - 1;
-  rng.request(2);
+  rng.request_jitter();
   double u = (j + random_double(rng)) / (cfg.image_width - 1);
   double v = (from_top_i + random_double(rng)) / (cfg.image_height - 1);
   Ray r = camera_get_ray(w.cam, u, v, rng);
@@ -788,17 +832,34 @@ double orc_mt_random_double(double a, double b) {
 }
 
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
-  philox4x32_10(ctr, key, out);
+  philox4x32(ctr, key, out, 10);
 }
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds) {
+  philox4x32(ctr, key, out, rounds);
+}
+int orc_philox_rounds(void) { return kPhiloxRounds; }
 
-// k-th double (k < n) of request `request` of n doubles
-double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t request, int n,
+// value k of request `request` of kind 0 = jitter (u, v, time), 1 = disk (y, x),
+// 2 = scatter (x, y, z, coin)
+double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t request, int kind,
                           int k) {
   PhiloxDraw g;
   g.seed = seed;
   g.begin_sample(pixel, sample);
   g.r = request;
-  g.request(n);
+  if (kind == 0) {
+    g.request_jitter();
+    return k == 2 ? g.stash_time : g.buf[k];
+  }
+  if (kind == 1) {
+    g.request_disk();
+    return g.buf[k];
+  }
+  if (k == 3) {
+    g.request_coin();
+    return g.buf[0];
+  }
+  g.request_scatter();
   return g.buf[k];
 }
 

@@ -62,7 +62,11 @@ uint64_t orc_raylog_count(void);
 
 /* Function-level probes (for unit tests). */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t request, int n,
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds);
+int orc_philox_rounds(void);
+/* value k of request `request`; kind 0 = jitter (u, v, time), 1 = disk (y, x),
+ * 2 = scatter candidate (x, y, z, coin) */
+double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t request, int kind,
                           int k);
 double orc_mt_random_double(double a, double b);
 /* returns 1 on hit and writes t, point[3], normal[3], front_facing */

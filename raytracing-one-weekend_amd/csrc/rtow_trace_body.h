@@ -31,13 +31,14 @@
 //     lane records the material index of every bounce in a per-lane path stack in
 //     HBM ([bounce][lane], coalesced) and folds it from the end when the path
 //     escapes to the sky.  A path that ends black contributes an exact zero.
-//   * RNG: Philox4x32-10 in REQUESTS — one block per draw site (pixel jitter: 2
-//     doubles, disk candidate: 2, shutter time: 1, unit-ball candidate: 3,
-//     dielectric coin: 1), counter (request, sample, pixel, 0), key = seed.  One
-//     block per request keeps the rejection loops free of per-lane parity
-//     divergence.  1-2 doubles map two words each like libstdc++'s
-//     generate_canonical<double,53> (src/random-utils.cpp:11-13); 3 doubles take 42
-//     bits each.
+//   * RNG: Philox4x32-7 in REQUESTS, one block each, counter (request, sample, pixel,
+//     0), key = seed: pixel jitter + shutter time share a block (42 bits each); every
+//     disk candidate takes one (two doubles, each from two words like libstdc++'s
+//     generate_canonical<double,53>, src/random-utils.cpp:11-13); every unit-ball
+//     candidate takes one (32 bits per coordinate) and the dielectric coin rides in the
+//     spare word of the bounce's first candidate.  Whole blocks per request keep the
+//     rejection loops free of per-lane parity divergence; Philox is ~1/4 of the
+//     kernel's VALU time, so blocks are not wasted.
 //
 // In the strict build (-ffp-contract=off) every expression below has the operand
 // order of the reference expression it restates, f64 sqrt and division are the
@@ -92,11 +93,15 @@ struct Rng {
   uint32_t pixel, sample, r;  // r = next request index of this sample
 };
 
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t &o0, uint32_t &o1,
-                                              uint32_t &o2, uint32_t &o3) {
+// Philox4x32-7: the fastest member of the family reported Crush-resistant (Salmon et al.,
+// SC'11); oracle/ uses the same round count (its tests pin the round function with the
+// published 10-round known answers).
+constexpr int kPhiloxRounds = 7;
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t &o0, uint32_t &o1,
+                                           uint32_t &o2, uint32_t &o3) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < kPhiloxRounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -124,42 +129,35 @@ __device__ __forceinline__ double canonical_from_words(uint32_t w0, uint32_t w1)
   return r;
 }
 
-// one request of 1 or 2 canonical doubles
-__device__ __forceinline__ void rng_request2(Rng &g, uint32_t k0, uint32_t k1, double &a, double &b) {
+// One request = one block (w0..w3); see oracle/rtow_oracle.cpp, struct PhiloxDraw.
+// jitter + shutter time: 42 bits each (word k + 10 bits of word 3)
+__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, double &u, double &v,
+                                           double &t) {
   uint32_t o0, o1, o2, o3;
-  philox4x32_10(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
+  const double s42 = 0x1p-42;
+  u = ((double)o0 + (double)(o3 & 1023u) * 4294967296.0) * s42;
+  v = ((double)o1 + (double)((o3 >> 10) & 1023u) * 4294967296.0) * s42;
+  t = ((double)o2 + (double)((o3 >> 20) & 1023u) * 4294967296.0) * s42;
+}
+// disk candidate: two doubles, each from two words like the reference's doubles
+__device__ __forceinline__ void rng_disk(Rng &g, uint32_t k0, uint32_t k1, double &a, double &b) {
+  uint32_t o0, o1, o2, o3;
+  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
   a = canonical_from_words(o0, o1);
   b = canonical_from_words(o2, o3);
 }
-__device__ __forceinline__ double rng_request1(Rng &g, uint32_t k0, uint32_t k1) {
+// unit-ball candidate (32 bits per coordinate); the spare word is the dielectric coin of
+// the bounce when this is its first candidate
+__device__ __forceinline__ V3 rng_scatter(Rng &g, uint32_t k0, uint32_t k1, double &coin) {
   uint32_t o0, o1, o2, o3;
-  philox4x32_10(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
-  return canonical_from_words(o0, o1);
-}
-// one request of 3 canonical doubles, 42 bits each
-__device__ __forceinline__ V3 rng_request3(Rng &g, uint32_t k0, uint32_t k1) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32_10(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
-  const double s42 = 0x1p-42;
-  V3 v;
-  v.x = ((double)o0 + (double)(o3 & 1023u) * 4294967296.0) * s42;
-  v.y = ((double)o1 + (double)((o3 >> 10) & 1023u) * 4294967296.0) * s42;
-  v.z = ((double)o2 + (double)((o3 >> 20) & 1023u) * 4294967296.0) * s42;
-  return v;
-}
-
-// src/random-utils.cpp:23-33: a point of [0,1)^3 inside the unit ball, not normalised
-__device__ __forceinline__ V3 rng_unit_vector(Rng &g, uint32_t k0, uint32_t k1) {
-  V3 v;
-  for (;;) {
-    v = rng_request3(g, k0, k1);
-    if (dot(v, v) >= 1.0) continue;
-    break;
-  }
-  return v;
+  const double s32 = 0x1p-32;
+  coin = (double)o3 * s32;
+  return V3{(double)o0 * s32, (double)o1 * s32, (double)o2 * s32};
 }
 
 // -------------------------------------------------------- primitive hit tests ---
@@ -532,15 +530,15 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
       g.r = 0u;
       // src/render.cpp:158-159
       const int from_top_i = P.H - (int)gi - 1;
-      double ju, jv;
-      rng_request2(g, k0, k1, ju, jv);
+      double ju, jv, jt;
+      rng_jitter(g, k0, k1, ju, jv, jt);
       const double u = ((double)(int)j + ju) / (double)(P.W - 1);
       const double v = ((double)from_top_i + jv) / (double)(P.H - 1);
       // src/common-model.cpp:156-167; disk sample: y draws first (random-utils.cpp:36)
       double px, py;
       for (;;) {
         double c0, c1;
-        rng_request2(g, k0, k1, c0, c1);
+        rng_disk(g, k0, k1, c0, c1);
         py = c0 * (1.0 - -1.0) + -1.0;
         px = c1 * (1.0 - -1.0) + -1.0;
         if (px * px + py * py + 0.0 * 0.0 >= 1.0) continue;
@@ -551,7 +549,7 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
       const V3 from = ld3(P.cam.origin) + offset;
       rd = ld3(P.cam.llc) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - from;
       ro = from;
-      rtime = rng_request1(g, k0, k1) * (P.cam.t1 - P.cam.t0) + P.cam.t0;
+      rtime = jt * (P.cam.t1 - P.cam.t0) + P.cam.t0;
       depth = P.max_child_rays;
       nb = 0;
       need_sample = false;
@@ -606,6 +604,9 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
           const int kind = m->kind;
 
           // ---- Material::scatter (src/common-model.cpp:13-62) ------------------
+          // first unit-ball candidate of this bounce; its block also carries the coin
+          double coin;
+          V3 rnd = rng_scatter(g, k0, k1, coin);
           V3 dirbase = {0.0, 0.0, 0.0};
           if (kind == 2) {
             const double ir = m->ir;
@@ -620,13 +621,17 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
               const double x = 1.0 - cos_theta;
               const double x2 = x * x;
               const double R = r0 + (1.0 - r0) * (x2 * x2 * x);
-              refl = R > rng_request1(g, k0, k1);
+              refl = R > coin;
             }
             dirbase = refl ? reflect(unit, normal) : refract(unit, normal, ratio);
           } else if (kind == 1) {
             dirbase = reflect(rd, normal);
           }
-          const V3 rnd = rng_unit_vector(g, k0, k1);
+          // random_unit_vector(): reject candidates outside the unit ball (random-utils.cpp:23-33)
+          while (dot(rnd, rnd) >= 1.0) {
+            double unused;
+            rnd = rng_scatter(g, k0, k1, unused);
+          }
           V3 dir;
           bool absorbed = false;
           if (kind == 0) {

@@ -194,8 +194,9 @@ def main():
     rng = np.random.default_rng(0)
     for tile in (False, True):
         ws = waves(tile)
-        pick = rng.choice(len(ws), size=60, replace=False)
+        pick = rng.choice(len(ws), size=25, replace=False)
         stats = []
+        ord_stats = []
         for wi in pick:
             lanes = [seglist[p] for p in ws[wi] if p in seglist]
             ntrips = min(en - st for st, en in lanes)
@@ -258,6 +259,33 @@ def main():
                     nxt = np.where(hit & ~isleaf, nn + 1, bvh["skip"][nn])
                     node = np.where(act, nxt, -1)
                 assert np.allclose(np.where(np.isinf(best), 1e30, best), np.where(np.isinf(bestl), 1e30, bestl))
+                # --- per-lane ORDERED traversal (visit = both children tested, near child first, stack) ---
+                ov = np.zeros(nl, dtype=np.int64); op = np.zeros(nl, dtype=np.int64)
+                for li in range(nl):
+                    bo = np.inf
+                    stk = [0]
+                    oo, dd, ii, aa = o[li], d[li], inv[li], a[li]
+                    while stk:
+                        n = stk.pop()
+                        if bvh["count"][n] > 0:
+                            for k in range(bvh["first"][n], bvh["first"][n] + bvh["count"][n]):
+                                pth = bvh["order"][k]
+                                op[li] += 1
+                                t = float(ptest(pth, oo[None], dd[None], np.array([aa]), np.array([bo]))[0])
+                                bo = min(bo, t)
+                            continue
+                        ov[li] += 1
+                        l, r_ = bvh["left"][n], bvh["right"][n]
+                        res = []
+                        for c in (l, r_):
+                            t0 = (bvh["lo"][c] - oo) * ii; t1 = (bvh["hi"][c] - oo) * ii
+                            near = max(np.minimum(t0, t1).max(), 1e-3); far = min(np.maximum(t0, t1).min(), bo)
+                            if near <= far:
+                                res.append((near, c))
+                        res.sort()
+                        for near, c in reversed(res):
+                            stk.append(c)
+                ord_stats.append((ov.mean(), ov.max(), op.mean(), op.max()))
                 nprim = (R[:, 2] == 0).sum()
                 stats.append((pv_nodes, pv_prims, steps.mean(), steps.max(), ptests.mean(), ptests.max(),
                               leaves.mean(), leaves.max(), nprim / nl))
@@ -272,6 +300,9 @@ def main():
         packet = S[:, 0] * 19 + S[:, 1] * per_test
         lane = S[:, 3] * 25 + S[:, 7] * (S[:, 5] / np.maximum(S[:, 7], 1)) * per_test
         print(f"  model VALU instr/trip: stream {stream}, packet {packet.mean():.0f}, per-lane(lockstep) {lane.mean():.0f}")
+        O = np.array(ord_stats)
+        print(f"  ORDERED per-lane: visits(2 boxes each) mean {O[:,0].mean():.2f} wave-max {O[:,1].mean():.2f}; prims mean {O[:,2].mean():.2f} wave-max {O[:,3].mean():.2f}")
+        print(f"  threaded: steps mean {S[:,2].mean():.2f} wave-max {S[:,3].mean():.2f}  -> cost 31*max = {31*S[:,3].mean():.0f}  vs ordered 56*max = {56*O[:,1].mean():.0f}")
 
 
 if __name__ == "__main__":

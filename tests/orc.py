@@ -59,6 +59,9 @@ def lib():
     L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32)]
     L.orc_philox4x32_10.restype = None
+    L.orc_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                 C.POINTER(C.c_uint32), C.c_int]
+    L.orc_philox4x32.restype = None
     L.orc_philox_request.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                      C.c_int]
     L.orc_philox_request.restype = C.c_double

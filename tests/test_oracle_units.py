@@ -40,24 +40,34 @@ def test_mt19937_stream_and_double_mapping():
 
 
 def test_philox_requests():
-    """A request is one Philox block: pure function of (seed, pixel, sample, request)."""
+    """A request is one Philox4x32-R block, a pure function of (seed, pixel, sample, request)."""
     L = orc.lib()
-    a = L.orc_philox_request(42, 1000, 7, 3, 2, 0)
-    assert a == L.orc_philox_request(42, 1000, 7, 3, 2, 0) and 0.0 <= a < 1.0
-    vals = {L.orc_philox_request(42, p, s, r, 2, k)
+    R = L.orc_philox_rounds()
+    assert R == 7
+    a = L.orc_philox_request(42, 1000, 7, 3, 1, 0)
+    assert a == L.orc_philox_request(42, 1000, 7, 3, 1, 0) and 0.0 <= a < 1.0
+    vals = {L.orc_philox_request(42, p, s, r, 1, k)
             for p in range(4) for s in range(4) for r in range(3) for k in range(2)}
     assert len(vals) == 96
-    assert L.orc_philox_request(43, 1000, 7, 3, 2, 0) != a
+    assert L.orc_philox_request(43, 1000, 7, 3, 1, 0) != a
     # the words of the block, by hand: counter (request, sample, pixel, 0), key = seed
     out = (C.c_uint32 * 4)()
-    L.orc_philox4x32_10((C.c_uint32 * 4)(3, 7, 1000, 0), (C.c_uint32 * 2)(42, 0), out)
+    L.orc_philox4x32((C.c_uint32 * 4)(3, 7, 1000, 0), (C.c_uint32 * 2)(42, 0), out, R)
     w = list(out)
-    assert L.orc_philox_request(42, 1000, 7, 3, 2, 0) == (w[0] + w[1] * 2.0**32) / 2.0**64
-    assert L.orc_philox_request(42, 1000, 7, 3, 2, 1) == (w[2] + w[3] * 2.0**32) / 2.0**64
-    # three doubles: 42 bits each (word k + 10 bits of word 3)
+    # disk: two doubles mapped like the reference maps two mt19937 words
+    assert L.orc_philox_request(42, 1000, 7, 3, 1, 0) == (w[0] + w[1] * 2.0**32) / 2.0**64
+    assert L.orc_philox_request(42, 1000, 7, 3, 1, 1) == (w[2] + w[3] * 2.0**32) / 2.0**64
+    # jitter + time: 42 bits each (word k + 10 bits of word 3)
     for k in range(3):
         want = (w[k] + ((w[3] >> (10 * k)) & 1023) * 2.0**32) / 2.0**42
-        assert L.orc_philox_request(42, 1000, 7, 3, 3, k) == want and want < 1.0
+        assert L.orc_philox_request(42, 1000, 7, 3, 0, k) == want and want < 1.0
+    # scatter candidate: 32 bits per coordinate, the coin in the spare word
+    for k in range(4):
+        assert L.orc_philox_request(42, 1000, 7, 3, 2, k) == w[k] / 2.0**32
+    # reduced-round blocks differ from the 10-round ones (the KAT test pins the round function)
+    out10 = (C.c_uint32 * 4)()
+    L.orc_philox4x32((C.c_uint32 * 4)(3, 7, 1000, 0), (C.c_uint32 * 2)(42, 0), out10, 10)
+    assert list(out10) != w
 
 
 def test_sphere_hit_cases():
