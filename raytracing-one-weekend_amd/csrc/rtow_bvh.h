@@ -307,7 +307,7 @@ inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
       size[i] = 1 + size[newidx[l]] + size[newidx[l + 1]];
     }
   }
-  const size_t nodes_bytes = (size_t)n * 32;
+  const size_t nodes_bytes = (size_t)(n + 1) * 32;  // + the sentinel END node
   const size_t ids_bytes = ((bvh.prim.size() * 4 + 15) / 16) * 16;
   img.off_ids = (uint32_t)nodes_bytes;
   img.off_sph = (uint32_t)(nodes_bytes + ids_bytes);
@@ -321,12 +321,12 @@ inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
     float rec[6];
     for (int k = 0; k < 3; ++k) {
       const double lo = bvh.box[(size_t)nd * 6 + k], hi = bvh.box[(size_t)nd * 6 + 3 + k];
-      const double pad = 1e-6 * scale + 1e-6 * std::max(std::fabs(lo), std::fabs(hi));
+      const double pad = 2e-6 * scale + 2e-6 * std::max(std::fabs(lo), std::fabs(hi));
       rec[k] = std::nextafterf((float)(lo - pad), -INFINITY);
       rec[3 + k] = std::nextafterf((float)(hi + pad), INFINITY);
     }
     const uint32_t nxt = (uint32_t)(i + size[i]);
-    const uint32_t skip = nxt >= (uint32_t)n ? 0xffffffffu : nxt;
+    const uint32_t skip = nxt >= (uint32_t)n ? (uint32_t)n : nxt;  // past the end = sentinel
     const int cnt = bvh.link[(size_t)nd * 4 + 1];
     const uint32_t leaf = cnt > 0 ? ((uint32_t)bvh.link[(size_t)nd * 4 + 0] << 3) | (uint32_t)cnt : 0u;
     unsigned char *dst = img.blob.data() + (size_t)i * 32;
@@ -334,10 +334,45 @@ inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
     std::memcpy(dst + 24, &skip, 4);
     std::memcpy(dst + 28, &leaf, 4);
   }
+  {  // sentinel END node: an empty box (never hit) whose skip link is itself, no leaf
+    const float inf = INFINITY;
+    const float rec[6] = {inf, inf, inf, -inf, -inf, -inf};
+    const uint32_t self = (uint32_t)n, leaf = 0u;
+    unsigned char *dst = img.blob.data() + (size_t)n * 32;
+    std::memcpy(dst, rec, 24);
+    std::memcpy(dst + 24, &self, 4);
+    std::memcpy(dst + 28, &leaf, 4);
+  }
   if (!bvh.prim.empty()) std::memcpy(img.blob.data() + img.off_ids, bvh.prim.data(), bvh.prim.size() * 4);
   if (!sph.empty()) std::memcpy(img.blob.data() + img.off_sph, sph.data(), sph.size() * 8);
   if (!mov.empty()) std::memcpy(img.blob.data() + img.off_mov, mov.data(), mov.size() * 8);
   if (!tri.empty()) std::memcpy(img.blob.data() + img.off_tri, tri.data(), tri.size() * 8);
+}
+
+// The kernel's termination argument rests on these: every skip link points forward and
+// at most to the end marker, leaves reference in-range primitive ids, ids are in range.
+inline bool validate_scene_image(const SceneImage &img, int n_prims) {
+  const uint32_t n = (uint32_t)img.n_nodes;
+  if (n == 0 || img.blob.size() < (size_t)(n + 1) * 32) return false;
+  for (uint32_t i = 0; i <= n; ++i) {
+    uint32_t skip, leaf;
+    std::memcpy(&skip, img.blob.data() + (size_t)i * 32 + 24, 4);
+    std::memcpy(&leaf, img.blob.data() + (size_t)i * 32 + 28, 4);
+    if (i == n) return skip == n && leaf == 0u;  // the END record
+    if (!(skip > i && skip <= n)) return false;
+    if (leaf != 0u) {
+      const uint32_t first = leaf >> 3, count = leaf & 7u;
+      if (count == 0u || first + count > (uint32_t)n_prims) return false;
+      for (uint32_t k = 0; k < count; ++k) {
+        int32_t id;
+        std::memcpy(&id, img.blob.data() + img.off_ids + 4 * (size_t)(first + k), 4);
+        if (id < 0 || id >= n_prims) return false;
+      }
+    } else if (i + 1 >= n) {
+      return false;  // an inner node needs a child at i+1
+    }
+  }
+  return true;
 }
 
 }  // namespace rtow

@@ -153,7 +153,7 @@ int rtow_ctx_create(int device_id, rtow_ctx **out) {
     for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreate(&c->ev[i][k]));
   for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreate(&c->call_ev[k]));
   c->ev_ready = true;
-  HIPCHK(hipHostMalloc((void **)&c->h_counters, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&c->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   *out = c;
   return RTOW_OK;
 }
@@ -272,6 +272,8 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max);
   rtow::SceneImage img;
   rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img);
+  if (!rtow::validate_scene_image(img, ns + nm + nt))
+    return fail(RTOW_EINVAL, "internal error: scene image failed validation (BVH links)");
 
   if ((rc = upload(c->sph, sph)) || (rc = upload(c->sph_r, sph_r)) || (rc = upload(c->mov, mov)) ||
       (rc = upload(c->tri, tri)) || (rc = upload(c->prim_mat, pmat)) || (rc = upload(c->mats, mats)) ||
@@ -445,6 +447,22 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.div_npix = make_fastdiv((uint32_t)npix);
   P.div_w = make_fastdiv((uint32_t)cfg->image_width);
   P.div_tile = make_fastdiv((uint32_t)cfg->tile_rows);
+  // tile the pixel order when the geometry allows it (a tile never straddles two strips)
+  uint32_t th = 0, tw = 0;
+  if (!std::getenv("RTOW_NO_TILES")) {
+    for (uint32_t h : {3u, 2u, 1u}) {
+      const uint32_t hh = 1u << h, ww = 64u >> h;
+      if (cfg->tile_rows % hh == 0 && rows % (int)hh == 0 && cfg->image_width % (int)ww == 0) {
+        th = h;
+        tw = 6u - h;
+        break;
+      }
+    }
+  }
+  P.tile_h_log2 = th;
+  P.tile_w_log2 = tw;
+  P.div_tpr_n = th ? (uint32_t)cfg->image_width >> tw : 1u;
+  P.div_tpr = make_fastdiv(P.div_tpr_n);
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
   P.counters = (unsigned long long *)c->counters.p;
@@ -467,12 +485,16 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   R.out = (double *)d_rgb_sums;
   R.npix3 = (uint32_t)(npix * 3);
   R.nstreams = cfg->nstreams;
+  R.W = (uint32_t)cfg->image_width;
+  R.tile_w_log2 = tw;
+  R.tile_h_log2 = th;
+  R.tiles_per_row = P.div_tpr_n;
   lrc = rtow::launch_reduce(R, st);
   if (lrc != 0) return fail(RTOW_EHIP, "reduce kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
 
   if (stats) {
     HIPCHK(hipEventRecord(c->call_ev[1], st));
-    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters.p, 4 * sizeof(unsigned long long),
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters.p, 8 * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0.f;

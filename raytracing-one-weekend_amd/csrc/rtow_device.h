@@ -67,16 +67,22 @@ struct TraceParams {
   uint32_t n_items;        // local_rows * W * nstreams
   uint32_t n_lanes;        // grid * block (stride of the path stack)
   FastDiv div_npix, div_w, div_tile;  // item -> (stream, row, column, strip)
+  // pixel order inside this rank's rows: tiles of 2^tile_w_log2 x 2^tile_h_log2 = 64 pixels,
+  // tiles row-major (tile_h_log2 == 0 and tile_w_log2 == 0: plain row-major order)
+  uint32_t tile_w_log2, tile_h_log2;
+  FastDiv div_tpr;         // tiles per row = W >> tile_w_log2
+  uint32_t div_tpr_n;      // the divisor itself
   double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests
 };
 
 struct ReduceParams {
-  const double *partials;
-  double *out;             // [local_rows*W][3]
+  const double *partials;  // [stream][tiled pixel][3]
+  double *out;             // [local_rows*W][3], row-major
   uint32_t npix3;          // local_rows*W*3
   int32_t nstreams;
+  uint32_t W, tile_w_log2, tile_h_log2, tiles_per_row;
 };
 
 // launchers, one pair per arithmetic mode (separate translation units compiled

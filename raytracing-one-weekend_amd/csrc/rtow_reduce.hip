@@ -10,8 +10,17 @@ namespace {
 __global__ void __launch_bounds__(256) rtow_reduce_streams(const ReduceParams p) {
   const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
   if (idx >= p.npix3) return;
+  // where this value sits in the (possibly tiled) item order of the trace kernel
+  uint32_t src = idx;
+  if (p.tile_h_log2 != 0u) {
+    const uint32_t px = idx / 3u, c = idx - px * 3u;
+    const uint32_t lr = px / p.W, j = px - lr * p.W;
+    const uint32_t tr = lr >> p.tile_h_log2, tc = j >> p.tile_w_log2;
+    const uint32_t w = ((lr & ((1u << p.tile_h_log2) - 1u)) << p.tile_w_log2) | (j & ((1u << p.tile_w_log2) - 1u));
+    src = (((tr * p.tiles_per_row + tc) << 6) | w) * 3u + c;
+  }
   double g = 0.0;
-  for (int k = 0; k < p.nstreams; ++k) g = p.partials[(size_t)k * p.npix3 + idx] + g;
+  for (int k = 0; k < p.nstreams; ++k) g = p.partials[(size_t)k * p.npix3 + src] + g;
   p.out[idx] = g;
 }
 }  // namespace

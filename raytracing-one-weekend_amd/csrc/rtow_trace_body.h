@@ -355,6 +355,10 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
   }
 }
 
+__device__ __forceinline__ unsigned lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
 template <bool LDS, bool ST>
 __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const DevScene &sc, V3 o,
                                                    V3 d, double time, bool active, uint32_t &nnode,
@@ -370,12 +374,15 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   const float tmin32 = 0.0009f;   // < RTOW_TMIN
   const float slack = 1.00002f;   // relative slack on the far side of the interval
   float tmax32 = __builtin_huge_valf();
-  const uint32_t END = 0xffffffffu;
+  const uint32_t END = (uint32_t)sc.n_nodes;  // skip links past the last node point here
   uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
   uint32_t q0 = 0u, q1 = 0u;  // queued leaves (0 = empty)
+  // Termination: every link of the image points forward (node+1 or skip > node, checked
+  // by the host at upload) and the walk stops at any index >= END, so a lane takes at
+  // most n_nodes steps.  (A per-trip guard counter here cost 7 % of the kernel.)
   for (;;) {
     if constexpr (ST) stamps.iters += 1;
-    if (node != END) {
+    if (node < END) {
       const float4 r0 = im.f4(node * 32u), r1 = im.f4(node * 32u + 16u);
       ++nnode;
       const float ax = fmaf(r0.x, ix, -oix), bx = fmaf(r0.w, ix, -oix);
@@ -393,7 +400,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
       }
       node = (hit && leaf == 0u) ? node + 1u : skip;
     }
-    const bool any_walking = __any(node != END);
+    const bool any_walking = __any(node < END);
     if (__any(q1 != 0u) || !any_walking) {
       stamps.mark(RG_WALK);
       if constexpr (ST) stamps.phases += 1;
@@ -420,10 +427,6 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDiv f) {
 }
 
 constexpr uint32_t kItemBatch = 64;  // work items fetched per global atomic (per wave)
-
-__device__ __forceinline__ unsigned lane_id() {
-  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
 
 // KERNEL: 1 = STREAM, 2 = BVH;  LDS: scene image staged in LDS (BVH only)
 template <int KERNEL, bool LDS, bool STAMPS = false>
@@ -506,8 +509,17 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
           item = (uint32_t)mine;
           const uint32_t k = fastdiv(item, P.div_npix);  // stream
           const uint32_t lp = item - k * npix_local;     // local pixel
-          const uint32_t lr = fastdiv(lp, P.div_w);
-          j = lp - lr * (uint32_t)P.W;
+          uint32_t lr;
+          if (P.tile_h_log2 == 0u) {  // row-major
+            lr = fastdiv(lp, P.div_w);
+            j = lp - lr * (uint32_t)P.W;
+          } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile
+            const uint32_t t = lp >> 6, w = lp & 63u;
+            const uint32_t tr = fastdiv(t, P.div_tpr);
+            const uint32_t tc = t - tr * (P.div_tpr_n);
+            lr = (tr << P.tile_h_log2) + (w >> P.tile_w_log2);
+            j = (tc << P.tile_w_log2) + (w & ((1u << P.tile_w_log2) - 1u));
+          }
           // local row -> global row: this rank's q-th strip is global strip q*nranks+rank
           const uint32_t q = fastdiv(lr, P.div_tile);
           const uint32_t rr = lr - q * (uint32_t)P.tile_rows;
