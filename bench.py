@@ -196,20 +196,24 @@ def main():
         # dominant kernel on THIS rank (rank 0): algorithmic bytes of its launch / its duration
         seg0 = float(st0.segments)
         fb_bytes = len(rows) * W * 24
-        if st0.kernel_used == rtow.KERNEL_BRUTE:
-            # streaming model: every wave of 64 segments streams the whole primitive array once
-            alg_bytes = math.ceil(seg0 / 64) * n_prims * BYTES_PER_SPHERE + fb_bytes
-            alg_flops = seg0 * n_prims * FLOPS_PER_SPHERE_TEST
-            model = "ceil(segments/64)*N_prim*32B + rows*W*24B (SURVEY.md §8d, f64 records)"
-            fmodel = "segments*N_prim*23 flop (sphere test to the discriminant reject)"
-        else:
-            # BVH model ('the unit becomes nodes+prims visited per segment'), from the
-            # kernel's own counters: every lane reads a 32 B node per box test and a 32 B record
-            # (+4 B id) per primitive test
-            alg_bytes = int(st0.node_tests) * BYTES_PER_NODE + int(st0.prim_tests) * (BYTES_PER_SPHERE + 4) + fb_bytes
-            alg_flops = int(st0.node_tests) * FLOPS_PER_BOX_TEST + int(st0.prim_tests) * FLOPS_PER_SPHERE_TEST
-            model = "node_tests*32B + prim_tests*36B + rows*W*24B (per-lane reads of the LDS scene image)"
-            fmodel = "node_tests*17 flop (f32 slab) + prim_tests*23 flop (f64 sphere test)"
+        # SURVEY.md §8d, the figure the metric is defined on: one unit = a wave of 64 segments
+        # streaming the primitive array once (f64 records: 32 B per sphere) + the framebuffer.
+        alg_bytes = math.ceil(seg0 / 64) * n_prims * BYTES_PER_SPHERE + fb_bytes
+        alg_flops = seg0 * n_prims * FLOPS_PER_SPHERE_TEST
+        model = "ceil(segments/64)*N_prim*32B + rows*W*24B (SURVEY.md §8d streaming model, f64 records)"
+        fmodel = "segments*N_prim*23 flop (sphere test to the discriminant reject, streaming model)"
+        walked = None
+        if st0.kernel_used == rtow.KERNEL_BVH:
+            # what the BVH kernel really reads and computes per launch (its own counters): every
+            # lane reads a 32 B node per box test and a 32 B record + 4 B id per primitive test,
+            # all from the LDS scene image
+            walked = {
+                "lds_bytes_per_launch": int(st0.node_tests) * BYTES_PER_NODE + int(st0.prim_tests) * (BYTES_PER_SPHERE + 4),
+                "flops_per_launch": int(st0.node_tests) * FLOPS_PER_BOX_TEST + int(st0.prim_tests) * FLOPS_PER_SPHERE_TEST,
+                "model": "node_tests*32B + prim_tests*36B ; node_tests*17 flop (f32 slab) + prim_tests*23 flop (f64)",
+            }
+            walked["lds_GBps"] = round(walked["lds_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1)
+            walked["TFLOPs"] = round(walked["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12, 3)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         prof = ROOT / "profiles" / "r01_hbm_traffic.json"
@@ -248,7 +252,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "model": model,
             },
-            "roofline_valu": {
+            "bvh_walk": walked,
+            "roofline_valu": None if walked else {
                 "bound": "valu_f64", "achieved": round(alg_flops / (kernel_ms * 1e-3) / 1e12, 3),
                 "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(alg_flops / (kernel_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TF, 5),

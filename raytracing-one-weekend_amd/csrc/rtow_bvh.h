@@ -61,6 +61,7 @@ struct Builder {
   HostBvh *out;
   static constexpr int kBins = 16;
   int leaf_max = 4;                      // <= 7 (3 bits in the leaf word)
+  double c_trav = 0.0;                   // cost of descending one level, in primitive tests
   static constexpr int kSahDepth = 48;   // below this depth fall back to median splits
 
   void set_node(int idx, const Box &b, int a, int c, int parent) {
@@ -144,8 +145,9 @@ struct Builder {
     }
     int mid = -1;
     if (best_axis >= 0) {
+      // SAH: split only if  C_trav + (A_L N_L + A_R N_R) / A_P  <  N   (costs in primitive tests)
       const double leaf_cost = b.half_area() * n;
-      if (n <= leaf_max && best_cost >= leaf_cost) {
+      if (n <= leaf_max && best_cost + c_trav * b.half_area() >= leaf_cost) {
         make_leaf();
         return;
       }
@@ -196,13 +198,14 @@ inline void pad_box(Box &b) {
 // sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
 inline void build_bvh(const std::vector<double> &sph, const std::vector<double> &sph_r,
                       const std::vector<double> &mov, const std::vector<double> &tri, HostBvh &out,
-                      int leaf_max = 4) {
+                      int leaf_max = 4, double c_trav = 0.0) {
   using namespace bvh_detail;
   const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
   const int n = ns + nm + nt;
   Builder B;
   B.out = &out;
   B.leaf_max = std::min(std::max(leaf_max, 1), 7);
+  B.c_trav = c_trav;
   B.pb.resize(n);
   B.cen.resize((size_t)n * 3);
   for (int i = 0; i < ns; ++i) {

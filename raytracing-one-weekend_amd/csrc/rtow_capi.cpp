@@ -113,7 +113,7 @@ struct rtow_ctx {
   rtow::DevCamera cam{};
   int n_prims = 0;
   // scene buffers
-  DevBuf sph, sph_r, mov, tri, prim_mat, mats, blob;
+  DevBuf sph, sph_r, mov, tri, prim_mat, mats, blob, cam_dev;
   uint32_t blob_bytes = 0;
   long long bvh_nodes = 0;
   // workspace
@@ -162,7 +162,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob,
+  for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev,
                     &c->partials, &c->stack, &c->counters})
     b->release();
   if (c->ev_ready) {
@@ -269,7 +269,9 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   rtow::HostBvh bvh;
   int leaf_max = 4;
   if (const char *e = std::getenv("RTOW_BVH_LEAF")) leaf_max = std::atoi(e);
-  rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max);
+  double c_trav = 0.0;
+  if (const char *e = std::getenv("RTOW_BVH_CT")) c_trav = std::atof(e);
+  rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav);
   rtow::SceneImage img;
   rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img);
   if (!rtow::validate_scene_image(img, ns + nm + nt))
@@ -316,6 +318,10 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   dc.lens_radius = k.lens_radius;
   dc.t0 = k.t0;
   dc.t1 = k.t1;
+  {
+    std::vector<rtow::DevCamera> one(1, dc);
+    if ((rc = upload(c->cam_dev, one))) return rc;
+  }
   c->have_scene = true;
   return RTOW_OK;
 }
@@ -430,7 +436,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   rtow::TraceParams P;
   std::memset(&P, 0, sizeof P);
   P.sc = c->ds;
-  P.cam = c->cam;
+  P.cam = (const rtow::DevCamera *)c->cam_dev.p;
   P.W = cfg->image_width;
   P.H = cfg->image_height;
   P.spt = spt;

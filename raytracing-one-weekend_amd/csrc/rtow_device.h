@@ -56,7 +56,8 @@ struct FastDiv {  // unsigned division by a per-launch constant (see fastdiv() i
 
 struct TraceParams {
   DevScene sc;
-  DevCamera cam;
+  const DevCamera *cam;    // in device memory: read with scalar loads where rays are generated
+                           // (by value it pinned 42 SGPRs across the whole kernel)
   int32_t W, H;            // full image
   int32_t spt;             // samples per stream (= spp / nstreams)
   int32_t nstreams;

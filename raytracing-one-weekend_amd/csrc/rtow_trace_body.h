@@ -556,12 +556,15 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
         if (px * px + py * py + 0.0 * 0.0 >= 1.0) continue;
         break;
       }
-      const double rdx = P.cam.lens_radius * px, rdy = P.cam.lens_radius * py;
-      const V3 offset = ld3(P.cam.u) * rdx + ld3(P.cam.v) * rdy;
-      const V3 from = ld3(P.cam.origin) + offset;
-      rd = ld3(P.cam.llc) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - from;
+      // camera block: wave-uniform scalar loads (origin u v horizontal vertical llc | lens t0 t1)
+      cdptr cm = (cdptr)(const double *)P.cam;
+      const double lens = cm[18], ct0 = cm[19], ct1 = cm[20];
+      const double rdx = lens * px, rdy = lens * py;
+      const V3 offset = V3{cm[3], cm[4], cm[5]} * rdx + V3{cm[6], cm[7], cm[8]} * rdy;
+      const V3 from = V3{cm[0], cm[1], cm[2]} + offset;
+      rd = V3{cm[15], cm[16], cm[17]} + u * V3{cm[9], cm[10], cm[11]} + v * V3{cm[12], cm[13], cm[14]} - from;
       ro = from;
-      rtime = jt * (P.cam.t1 - P.cam.t0) + P.cam.t0;
+      rtime = jt * (ct1 - ct0) + ct0;
       depth = P.max_child_rays;
       nb = 0;
       need_sample = false;
