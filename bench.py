@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
     ap.add_argument("--precision", choices=["fast", "strict"], default="fast")
-    ap.add_argument("--kernel", choices=["auto", "brute", "bvh"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid"], default="auto")
     ap.add_argument("--moving", action="store_true", help="moving-sphere variant of the cover scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -132,7 +132,7 @@ def main():
     nstreams = max(1, spp // SAMPLES_PER_ITEM)
     tile_rows = 4 if H % (4 * world) == 0 else 8
     precision = rtow.F64_FAST if a.precision == "fast" else rtow.F64_STRICT
-    kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH}[a.kernel]
+    kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID}[a.kernel]
     cfg = rtow.make_config(W, H, spp, nstreams, DEPTH, seed=SEED, precision=precision,
                            kernel=kernel, rank=rank, nranks=world, tile_rows=tile_rows)
 
@@ -203,7 +203,7 @@ def main():
         model = "ceil(segments/64)*N_prim*32B + rows*W*24B (SURVEY.md §8d streaming model, f64 records)"
         fmodel = "segments*N_prim*23 flop (sphere test to the discriminant reject, streaming model)"
         walked = None
-        if st0.kernel_used == rtow.KERNEL_BVH:
+        if st0.kernel_used in (rtow.KERNEL_BVH, rtow.KERNEL_GRID):
             # what the BVH kernel really reads and computes per launch (its own counters): every
             # lane reads a 32 B node per box test and a 32 B record + 4 B id per primitive test,
             # all from the LDS scene image
@@ -239,7 +239,8 @@ def main():
                 "spp_effective": spp_eff, "samples_per_item": spp // nstreams, "nstreams": nstreams,
                 "seed": SEED, "precision": a.precision,
                 "kernel": {1: "stream (every lane tests every primitive, scalar-load broadcast)",
-                           2: "bvh (per-lane threaded walk of the LDS scene image)"}[st0.kernel_used],
+                           2: "bvh (per-lane threaded walk of the LDS scene image)",
+                           3: "grid (per-lane 3D-DDA over the LDS scene image + large-primitive list)"}[st0.kernel_used],
                 "segments_per_sample": round(segments / samples, 4),
                 "node_tests_per_segment": round(st0.node_tests / max(seg0, 1), 3),
                 "prim_tests_per_segment": round(st0.prim_tests / max(seg0, 1), 3),

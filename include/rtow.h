@@ -58,6 +58,8 @@ extern "C" {
 #define RTOW_KERNEL_AUTO 0
 #define RTOW_KERNEL_BRUTE 1 /* every ray tests every primitive (wave-uniform stream)   */
 #define RTOW_KERNEL_BVH 2   /* every lane walks a threaded (stackless) BVH in LDS       */
+#define RTOW_KERNEL_GRID 3  /* every lane walks a uniform grid (3D-DDA) in LDS; falls back
+                               to BVH when the scene does not suit a grid              */
 
 /* Camera state: exactly the private members of the reference Camera after its
  * constructor ran (src/common-model.h:104-112, src/common-model.cpp:136-154). */

@@ -48,6 +48,10 @@ struct DevScene {
   uint32_t blob_bytes;
   uint32_t off_ids, off_sph, off_mov, off_tri;
   int32_t n_nodes;
+  // scene image for the GRID kernel (rtow_grid.h): header, cells, ids, records
+  const unsigned char *gblob;
+  uint32_t gblob_bytes;
+  uint32_t g_off_cells, g_off_ids, g_off_sph, g_off_mov, g_off_tri;
 };
 
 struct FastDiv {  // unsigned division by a per-launch constant (see fastdiv() in the kernel)

@@ -1,0 +1,189 @@
+// rtow_grid.h — host build of the uniform-grid scene image (kernel RTOW_KERNEL_GRID).
+//
+// Why a grid next to the BVH: in the reference's scenes (hundreds of small primitives
+// spread over a ground plane, or one compact mesh) most rays start INSIDE the bounds of
+// the small primitives, so a BVH walk first descends ~2·log2(N) boxes that merely contain
+// the ray origin before it learns anything.  A 3D-DDA starts in the origin's cell and
+// visits a handful of mostly empty cells.  Primitives much larger than the rest (the
+// r = 1000 ground sphere) would occupy every cell, so they go to a short "large" list
+// that every ray tests first.  Leaf tests are the same f64 code as the other kernels, and
+// primitives are registered in every cell their PADDED bounds touch, so the set of
+// candidates is conservative and the accepted (t, primitive) is identical.
+//
+// Blob layout (16-byte aligned sections):
+//   [header 64 B][cells ncell x 4 B][ids][sphere 32 B][moving 64 B][triangle 96 B records]
+//   header : f32 gmin[3], f32 cell[3], f32 inv_cell[3], i32 n[3], u32 n_large, u32 off_large,
+//            pad (off_large = byte offset of the large-primitive id list inside [ids])
+//   cell   : u32 (first << 8 | count) into the id section, 0 = empty
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace rtow {
+
+struct GridImage {
+  std::vector<unsigned char> blob;
+  uint32_t off_cells = 0, off_ids = 0, off_sph = 0, off_mov = 0, off_tri = 0;
+  int32_t n[3] = {1, 1, 1};
+  uint32_t n_large = 0;
+  bool ok = false;  // false: scene not suited (e.g. lists too long) — use the BVH
+};
+
+namespace grid_detail {
+struct B3 {
+  double mn[3], mx[3];
+};
+}  // namespace grid_detail
+
+// sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
+inline void build_grid_image(const std::vector<double> &sph, const std::vector<double> &sph_r,
+                             const std::vector<double> &mov, const std::vector<double> &tri,
+                             const double cam_origin[3], GridImage &img, double cells_per_prim = 1.5,
+                             double large_ratio = 4.0) {
+  using grid_detail::B3;
+  const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
+  const int np = ns + nm + nt;
+  img.ok = false;
+  if (np == 0) return;
+  std::vector<B3> pb(np);
+  for (int i = 0; i < ns; ++i) {
+    const double r = std::fabs(sph_r[i]);
+    for (int k = 0; k < 3; ++k) {
+      pb[i].mn[k] = sph[(size_t)i * 4 + k] - r;
+      pb[i].mx[k] = sph[(size_t)i * 4 + k] + r;
+    }
+  }
+  for (int i = 0; i < nm; ++i) {  // bound the motion over time in [-1, 2] ⊇ any shutter in [0,1]
+    const double *m = &mov[(size_t)i * 8];
+    const double r = std::fabs(m[7]);
+    for (int k = 0; k < 3; ++k) {
+      const double a0 = m[k] - m[3 + k], a1 = m[k] + 2.0 * m[3 + k];
+      pb[ns + i].mn[k] = std::min(a0, a1) - r;
+      pb[ns + i].mx[k] = std::max(a0, a1) + r;
+    }
+  }
+  for (int i = 0; i < nt; ++i) {
+    const double *t = &tri[(size_t)i * 12];
+    for (int k = 0; k < 3; ++k) {
+      const double a = t[k], b = t[k] + t[3 + k], c = t[k] + t[6 + k];
+      pb[ns + nm + i].mn[k] = std::min(a, std::min(b, c));
+      pb[ns + nm + i].mx[k] = std::max(a, std::max(b, c));
+    }
+  }
+  // large primitives: bounding-box diagonal > large_ratio x the median diagonal (cover scene:
+  // the ground sphere and the three r = 1 spheres; the grid then only spans the thin slab of
+  // r = 0.2 spheres, which most rays leave after one or two cells)
+  std::vector<double> diag(np);
+  for (int i = 0; i < np; ++i) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (pb[i].mx[k] - pb[i].mn[k]) * (pb[i].mx[k] - pb[i].mn[k]);
+    diag[i] = std::sqrt(s);
+  }
+  std::vector<double> sorted = diag;
+  std::nth_element(sorted.begin(), sorted.begin() + np / 2, sorted.end());
+  const double med = std::max(sorted[np / 2], 1e-12);
+  std::vector<int32_t> large, small;
+  for (int i = 0; i < np; ++i) (diag[i] > large_ratio * med ? large : small).push_back(i);
+  if (small.empty() || large.size() > 64) return;
+
+  // grid bounds = bounds of the small primitives
+  double gmn[3] = {INFINITY, INFINITY, INFINITY}, gmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i : small)
+    for (int k = 0; k < 3; ++k) {
+      gmn[k] = std::min(gmn[k], pb[i].mn[k]);
+      gmx[k] = std::max(gmx[k], pb[i].mx[k]);
+    }
+  // the f32 DDA sees the ray rounded to f32: pad by more than that rounding can move the ray
+  // or a cell boundary anywhere in the scene (same reasoning as the BVH boxes, rtow_bvh.h)
+  double scale = 1.0;
+  for (int k = 0; k < 3; ++k) {
+    scale = std::max(scale, std::max(std::fabs(gmn[k]), std::fabs(gmx[k])));
+    scale = std::max(scale, std::fabs(cam_origin[k]));
+    for (int i : large) scale = std::max(scale, std::max(std::fabs(pb[i].mn[k]), std::fabs(pb[i].mx[k])));
+  }
+  const double pad = 4e-6 * scale;
+  double ext[3];
+  for (int k = 0; k < 3; ++k) {
+    gmn[k] -= 2 * pad;
+    gmx[k] += 2 * pad;
+    ext[k] = std::max(gmx[k] - gmn[k], 1e-9);
+  }
+  const double target = std::min(std::max(cells_per_prim * (double)small.size(), 8.0), 32768.0);
+  const double s = std::cbrt(ext[0] * ext[1] * ext[2] / target);
+  long long ncell = 1;
+  float cellf[3], gminf[3], invf[3];
+  for (int k = 0; k < 3; ++k) {
+    int nk = (int)std::ceil(ext[k] / s);
+    nk = std::min(std::max(nk, 1), 128);
+    img.n[k] = nk;
+    ncell *= nk;
+    gminf[k] = std::nextafterf((float)gmn[k], -INFINITY);
+    // cell size as f32, rounded up so n*cell covers the extent
+    cellf[k] = std::nextafterf((float)((gmx[k] - (double)gminf[k]) / nk), INFINITY);
+    invf[k] = 1.0f / cellf[k];
+  }
+  // register every small primitive in all cells its padded bounds touch (computed with the
+  // same f32 gmin/cell the kernel uses, widened by one ulp-ish margin through `pad`)
+  std::vector<std::vector<int32_t>> lists((size_t)ncell);
+  for (int i : small) {
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+      const double a = (pb[i].mn[k] - pad - (double)gminf[k]) / (double)cellf[k];
+      const double b = (pb[i].mx[k] + pad - (double)gminf[k]) / (double)cellf[k];
+      lo[k] = std::min(std::max((int)std::floor(a), 0), img.n[k] - 1);
+      hi[k] = std::min(std::max((int)std::floor(b), 0), img.n[k] - 1);
+    }
+    for (int z = lo[2]; z <= hi[2]; ++z)
+      for (int y = lo[1]; y <= hi[1]; ++y)
+        for (int x = lo[0]; x <= hi[0]; ++x)
+          lists[((size_t)z * img.n[1] + y) * img.n[0] + x].push_back(i);
+  }
+  size_t total_ids = large.size();
+  for (auto &l : lists) {
+    if (l.size() > 255) return;  // too dense for the 8-bit count: let the BVH handle this scene
+    total_ids += l.size();
+  }
+  if (total_ids >= (1u << 24)) return;
+
+  const size_t hdr = 64;
+  img.off_cells = (uint32_t)hdr;
+  const size_t cells_bytes = (((size_t)ncell * 4 + 15) / 16) * 16;
+  img.off_ids = (uint32_t)(hdr + cells_bytes);
+  const size_t ids_bytes = ((total_ids * 4 + 15) / 16) * 16;
+  img.off_sph = (uint32_t)(img.off_ids + ids_bytes);
+  img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
+  img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
+  const size_t total = (size_t)img.off_tri + tri.size() * 8;
+  img.blob.assign(((total + 15) / 16) * 16, 0);
+  img.n_large = (uint32_t)large.size();
+
+  std::vector<int32_t> ids;
+  ids.reserve(total_ids);
+  std::vector<uint32_t> cells((size_t)ncell, 0u);
+  for (size_t c = 0; c < (size_t)ncell; ++c) {
+    if (lists[c].empty()) continue;
+    cells[c] = ((uint32_t)ids.size() << 8) | (uint32_t)lists[c].size();
+    ids.insert(ids.end(), lists[c].begin(), lists[c].end());
+  }
+  const uint32_t off_large = (uint32_t)(img.off_ids + ids.size() * 4);
+  ids.insert(ids.end(), large.begin(), large.end());
+
+  unsigned char *h = img.blob.data();
+  std::memcpy(h + 0, gminf, 12);
+  std::memcpy(h + 12, cellf, 12);
+  std::memcpy(h + 24, invf, 12);
+  std::memcpy(h + 36, img.n, 12);
+  std::memcpy(h + 48, &img.n_large, 4);
+  std::memcpy(h + 52, &off_large, 4);
+  std::memcpy(h + img.off_cells, cells.data(), cells.size() * 4);
+  if (!ids.empty()) std::memcpy(h + img.off_ids, ids.data(), ids.size() * 4);
+  if (!sph.empty()) std::memcpy(h + img.off_sph, sph.data(), sph.size() * 8);
+  if (!mov.empty()) std::memcpy(h + img.off_mov, mov.data(), mov.size() * 8);
+  if (!tri.empty()) std::memcpy(h + img.off_tri, tri.data(), tri.size() * 8);
+  img.ok = true;
+}
+
+}  // namespace rtow

@@ -326,37 +326,42 @@ __device__ __forceinline__ float safe_inv(float d) {
   return fabsf(d) < 1e-30f ? (__builtin_signbitf(d) ? -big : big) : 1.0f / d;
 }
 
+struct ImgOffsets {  // byte offsets of the id and record sections inside a scene image
+  uint32_t ids, sph, mov, tri;
+};
+
+// Tests primitives ids[first .. first+count) of a scene image against the ray (f64, the same
+// code as the STREAM kernel, so the accepted (t, primitive) is the same).
 template <bool LDS>
-__device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, uint32_t leaf,
-                                          V3 o, V3 d, double a, double inv_a, double time,
-                                          Closest &best, uint32_t &nprim) {
-  const uint32_t first = leaf >> 3, count = leaf & 7u;
+__device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, ImgOffsets off,
+                                          uint32_t first, uint32_t count, V3 o, V3 d, double a,
+                                          double inv_a, double time, Closest &best, uint32_t &nprim,
+                                          int &last_id) {
   for (uint32_t k = 0; k < count; ++k) {
-    const int id = (int)im.u32(sc.off_ids + 4u * (first + k));
+    const int id = (int)im.u32(off.ids + 4u * (first + k));
+    // one-entry mailbox: a primitive spanning adjacent grid cells is listed in each of them
+    if (id == last_id) continue;
+    last_id = id;
     ++nprim;
     if (id < sc.n_sph) {
-      const uint32_t off = sc.off_sph + 32u * (uint32_t)id;
-      const double2 p0 = im.d2(off), p1 = im.d2(off + 16u);
+      const uint32_t r = off.sph + 32u * (uint32_t)id;
+      const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
       sphere_test(o, d, a, inv_a, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
     } else if (id < sc.n_sph + sc.n_mov) {
-      const uint32_t off = sc.off_mov + 64u * (uint32_t)(id - sc.n_sph);
-      const double2 p0 = im.d2(off), p1 = im.d2(off + 16u), p2 = im.d2(off + 32u), p3 = im.d2(off + 48u);
+      const uint32_t r = off.mov + 64u * (uint32_t)(id - sc.n_sph);
+      const double2 p0 = im.d2(r), p1 = im.d2(r + 16u), p2 = im.d2(r + 32u), p3 = im.d2(r + 48u);
       const double cx = p0.x + time * p1.y;
       const double cy = p0.y + time * p2.x;
       const double cz = p1.x + time * p2.y;
       sphere_test(o, d, a, inv_a, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
     } else {
-      const uint32_t off = sc.off_tri + 96u * (uint32_t)(id - sc.n_sph - sc.n_mov);
-      const double2 q0 = im.d2(off), q1 = im.d2(off + 16u), q2 = im.d2(off + 32u),
-                    q3 = im.d2(off + 48u), q4 = im.d2(off + 64u), q5 = im.d2(off + 80u);
+      const uint32_t r = off.tri + 96u * (uint32_t)(id - sc.n_sph - sc.n_mov);
+      const double2 q0 = im.d2(r), q1 = im.d2(r + 16u), q2 = im.d2(r + 32u), q3 = im.d2(r + 48u),
+                    q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
       triangle_test(o, d, V3{q0.x, q0.y, q1.x}, V3{q1.y, q2.x, q2.y}, V3{q3.x, q3.y, q4.x},
                     V3{q4.y, q5.x, q5.y}, id, RTOW_TMIN, best);
     }
   }
-}
-
-__device__ __forceinline__ unsigned lane_id() {
-  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
 template <bool LDS, bool ST>
@@ -375,6 +380,8 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   const float slack = 1.00002f;   // relative slack on the far side of the interval
   float tmax32 = __builtin_huge_valf();
   const uint32_t END = (uint32_t)sc.n_nodes;  // skip links past the last node point here
+  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri};
+  int last_id = -1;
   uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
   uint32_t q0 = 0u, q1 = 0u;  // queued leaves (0 = empty)
   // Termination: every link of the image points forward (node+1 or skip > node, checked
@@ -406,10 +413,111 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
       if constexpr (ST) stamps.phases += 1;
       // leaf phase: every lane tests the primitives of the OLDEST leaf it queued (most
       // lanes hold one; only the lanes whose queue filled hold two, and theirs moves up)
-      if (q0 != 0u) leaf_test(im, sc, q0, o, d, a, inv_a, time, best, nprim);
+      if (q0 != 0u) leaf_test(im, sc, off, q0 >> 3, q0 & 7u, o, d, a, inv_a, time, best, nprim, last_id);
       q0 = q1;
       q1 = 0u;
       // shrink the f32 interval (rounded up: never below the f64 value)
+      tmax32 = __double2float_ru(best.t);
+      stamps.mark(RG_LEAF);
+      if (!any_walking && !__any(q0 != 0u)) break;
+    }
+  }
+  return best;
+}
+
+// --------------------------------------------------------- closest hit: GRID ---
+// 3D-DDA over the uniform grid of rtow_grid.h.  Primitives far larger than the rest (the
+// ground sphere) are not in the grid; every ray tests that short list first.  Cells are
+// visited in order along the ray; a non-empty cell is queued like a BVH leaf and tested in
+// the SIMT-dense leaf phase.  The walk ends when the ray leaves the grid (integer cell
+// counters, so at most nx+ny+nz steps whatever the floats do) or when the exit distance of
+// the current cell is beyond the closest hit so far.
+template <bool LDS, bool ST>
+__device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const DevScene &sc, V3 o,
+                                                    V3 d, double time, bool active, uint32_t &nnode,
+                                                    uint32_t &nprim, Stamps<ST> &stamps) {
+  Closest best;
+  best.t = __builtin_huge_val();
+  best.prim = -1;
+  const double a = dot(d, d);
+  const double inv_a = 1.0 / a;
+  const ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri};
+  int last_id = -1;
+  // header: wave-uniform scalar loads from the global copy of the image
+  const RTOW_CONST float *hf = (const RTOW_CONST float *)sc.gblob;
+  const RTOW_CONST int32_t *hi = (const RTOW_CONST int32_t *)sc.gblob;
+  const float gx = hf[0], gy = hf[1], gz = hf[2];
+  const float cx = hf[3], cy = hf[4], cz = hf[5];
+  const float icx = hf[6], icy = hf[7], icz = hf[8];
+  const int nx = hi[9], ny = hi[10], nz = hi[11];
+  const uint32_t n_large = (uint32_t)hi[12], off_large = (uint32_t)hi[13];
+
+  // the large primitives, for every ray
+  if (active && n_large != 0u)
+    leaf_test(im, sc, off, (off_large - off.ids) >> 2, n_large, o, d, a, inv_a, time, best, nprim, last_id);
+  float tmax32 = __double2float_ru(best.t);
+
+  // clip the ray to the grid bounds (f32, conservative by the padding of rtow_grid.h)
+  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+  const float oix = ox * ix, oiy = oy * iy, oiz = oz * iz;
+  const float hx = fmaf((float)nx, cx, gx), hy = fmaf((float)ny, cy, gy), hz = fmaf((float)nz, cz, gz);
+  const float ax = fmaf(gx, ix, -oix), bx = fmaf(hx, ix, -oix);
+  const float ay = fmaf(gy, iy, -oiy), by = fmaf(hy, iy, -oiy);
+  const float az = fmaf(gz, iz, -oiz), bz = fmaf(hz, iz, -oiz);
+  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0009f));
+  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax32));
+  bool walking = active && t0 <= t1 * 1.00002f;
+
+  // starting cell and DDA state
+  const float px = fmaf(t0, dx, ox), py = fmaf(t0, dy, oy), pz = fmaf(t0, dz, oz);
+  int c0 = (int)floorf((px - gx) * icx), c1 = (int)floorf((py - gy) * icy), c2 = (int)floorf((pz - gz) * icz);
+  c0 = min(max(c0, 0), nx - 1);
+  c1 = min(max(c1, 0), ny - 1);
+  c2 = min(max(c2, 0), nz - 1);
+  const bool fx = dx >= 0.0f, fy = dy >= 0.0f, fz = dz >= 0.0f;
+  float tmx = fmaf(fmaf((float)(c0 + (fx ? 1 : 0)), cx, gx), ix, -oix);
+  float tmy = fmaf(fmaf((float)(c1 + (fy ? 1 : 0)), cy, gy), iy, -oiy);
+  float tmz = fmaf(fmaf((float)(c2 + (fz ? 1 : 0)), cz, gz), iz, -oiz);
+  const float tdx = fabsf(cx * ix), tdy = fabsf(cy * iy), tdz = fabsf(cz * iz);
+  int remx = fx ? nx - 1 - c0 : c0, remy = fy ? ny - 1 - c1 : c1, remz = fz ? nz - 1 - c2 : c2;
+  const int incx = fx ? 1 : -1, incy = fy ? nx : -nx, incz = fz ? nx * ny : -(nx * ny);
+  int idx = (c2 * ny + c1) * nx + c0;
+
+  uint32_t q0 = 0u, q1 = 0u;
+  for (;;) {
+    if constexpr (ST) stamps.iters += 1;
+    if (walking) {
+      const uint32_t cw = im.u32(sc.g_off_cells + 4u * (uint32_t)idx);
+      ++nnode;
+      if (cw != 0u) {
+        if (q0 == 0u)
+          q0 = cw;
+        else
+          q1 = cw;
+      }
+      // leave through the nearest cell wall
+      const bool sx = tmx <= tmy && tmx <= tmz;
+      const bool sy = !sx && tmy <= tmz;
+      const float tnext = sx ? tmx : (sy ? tmy : tmz);
+      const int rem = sx ? remx : (sy ? remy : remz);
+      walking = rem > 0 && !(tnext > tmax32);
+      idx += sx ? incx : (sy ? incy : incz);
+      tmx += sx ? tdx : 0.0f;
+      tmy += sy ? tdy : 0.0f;
+      tmz += (!sx && !sy) ? tdz : 0.0f;
+      remx -= sx ? 1 : 0;
+      remy -= sy ? 1 : 0;
+      remz -= (!sx && !sy) ? 1 : 0;
+    }
+    const bool any_walking = __any(walking);
+    if (__any(q1 != 0u) || !any_walking) {
+      stamps.mark(RG_WALK);
+      if constexpr (ST) stamps.phases += 1;
+      if (q0 != 0u) leaf_test(im, sc, off, q0 >> 8, q0 & 255u, o, d, a, inv_a, time, best, nprim, last_id);
+      q0 = q1;
+      q1 = 0u;
       tmax32 = __double2float_ru(best.t);
       stamps.mark(RG_LEAF);
       if (!any_walking && !__any(q0 != 0u)) break;
@@ -428,9 +536,13 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDiv f) {
 
 constexpr uint32_t kItemBatch = 64;  // work items fetched per global atomic (per wave)
 
+__device__ __forceinline__ unsigned lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
 // KERNEL: 1 = STREAM, 2 = BVH;  LDS: scene image staged in LDS (BVH only)
 template <int KERNEL, bool LDS, bool STAMPS = false>
-__global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
+__global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const TraceParams P) {
   const DevScene &sc = P.sc;
   const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
@@ -439,12 +551,12 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
   const uint32_t npix_local = (uint32_t)P.local_rows * (uint32_t)P.W;
 
   Image<LDS> im;
-  im.g = sc.blob;
-  if constexpr (KERNEL == 2 && LDS) {
+  im.g = KERNEL == 3 ? sc.gblob : sc.blob;
+  if constexpr (KERNEL >= 2 && LDS) {
     // stage the scene image: coalesced 16-byte loads, 16-byte LDS stores
-    const uint4 *src = reinterpret_cast<const uint4 *>(sc.blob);
+    const uint4 *src = reinterpret_cast<const uint4 *>(im.g);
     uint4 *dst = reinterpret_cast<uint4 *>(rtow_lds);
-    const uint32_t n16 = sc.blob_bytes / 16u;
+    const uint32_t n16 = (KERNEL == 3 ? sc.gblob_bytes : sc.blob_bytes) / 16u;
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
   }
@@ -576,7 +688,9 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
     Closest best;
     best.t = 0.0;
     best.prim = -1;
-    if constexpr (KERNEL == 2) {
+    if constexpr (KERNEL == 3) {
+      best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
+    } else if constexpr (KERNEL == 2) {
       // the walk uses wave votes, so every lane of the wave enters it
       best = closest_hit_bvh<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
     } else {
@@ -706,7 +820,7 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
   }
   if (lane == 0) {
     atomicAdd(&P.counters[1], t0);
-    if (KERNEL == 2) {
+    if (KERNEL >= 2) {
       atomicAdd(&P.counters[2], t1);
       atomicAdd(&P.counters[3], t2);
     }
@@ -715,35 +829,33 @@ __global__ void __launch_bounds__(KERNEL == 2 ? 1024 : 256)
 
 }  // namespace
 
+// kernel: 1 STREAM, 2 BVH, 3 GRID; +16 = diagnostic region stamps (LDS variants only)
+template <int K, bool L, bool S>
+static int launch_one(const TraceParams &p, int grid, int block, unsigned lds_bytes, hipStream_t st) {
+  auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<K, L, S>;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, st, p);
+  return (int)hipGetLastError();
+}
+
 int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int grid, int block,
                                          unsigned lds_bytes, void *stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (kernel == 3) {  // diagnostic: BVH + LDS image + region stamps
-    auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true, true>;
-    if (lds_bytes > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, st, p);
-    return (int)hipGetLastError();
+  const bool lds = lds_bytes > 0;
+  switch (kernel) {
+    case 1: return launch_one<1, false, false>(p, grid, block, 0, st);
+    case 2: return lds ? launch_one<2, true, false>(p, grid, block, lds_bytes, st)
+                       : launch_one<2, false, false>(p, grid, block, 0, st);
+    case 3: return lds ? launch_one<3, true, false>(p, grid, block, lds_bytes, st)
+                       : launch_one<3, false, false>(p, grid, block, 0, st);
+    case 2 + 16: return launch_one<2, true, true>(p, grid, block, lds_bytes, st);
+    case 3 + 16: return launch_one<3, true, true>(p, grid, block, lds_bytes, st);
+    default: return (int)hipErrorInvalidValue;
   }
-  if (kernel == 2) {
-    if (lds_bytes > 0) {
-      auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true>;
-      if (lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-      }
-      hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, st, p);
-    } else {
-      hipLaunchKernelGGL((RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, false>), dim3(grid), dim3(block), 0, st, p);
-    }
-  } else {
-    hipLaunchKernelGGL((RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<1, false>), dim3(grid), dim3(block), 0, st, p);
-  }
-  return (int)hipGetLastError();
 }
 
 // Workgroups per CU that stay resident: min over the register file (512 VGPRs per
@@ -753,18 +865,17 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
 // find the work queue empty — there is no inter-workgroup dependency.)
 int RTOW_CAT(trace_occupancy_, RTOW_SUFFIX)(int kernel, int block, unsigned lds_bytes) {
   const void *fn;
-  if (kernel == 2 && lds_bytes > 0) {
-    auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true>;
-    fn = reinterpret_cast<const void *>(k);
-    if (lds_bytes > 48 * 1024)
-      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  } else if (kernel == 2) {
-    auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, false>;
-    fn = reinterpret_cast<const void *>(k);
-  } else {
-    auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<1, false>;
-    fn = reinterpret_cast<const void *>(k);
-  }
+  const bool lds = lds_bytes > 0;
+  if (kernel == 3)
+    fn = lds ? reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<3, true, false>)
+             : reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<3, false, false>);
+  else if (kernel == 2)
+    fn = lds ? reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, true, false>)
+             : reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<2, false, false>);
+  else
+    fn = reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<1, false, false>);
+  if (lds_bytes > 48 * 1024)
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   hipFuncAttributes fa;
   if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return -1;
   const int regs = fa.numRegs > 0 ? fa.numRegs : 128;

@@ -22,7 +22,7 @@ RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY = 0, -1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
 F64_STRICT, F64_FAST = 0, 1
-KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH = 0, 1, 2
+KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH, KERNEL_GRID = 0, 1, 2, 3
 
 d3 = C.c_double * 3
 _pd = C.POINTER(C.c_double)

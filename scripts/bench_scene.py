@@ -34,7 +34,7 @@ W = a.width or W; spp = a.spp or spp; depth = a.depth or depth
 H = rtow.image_height(W, aspect)
 cfg = rtow.make_config(W, H, spp, max(1, spp // 8 if a.scene in ("suzanne", "mesh100k") else spp // 10), depth, seed=1,
                        precision=rtow.F64_FAST if a.precision == "fast" else rtow.F64_STRICT,
-                       kernel={"auto": 0, "brute": 1, "bvh": 2}[a.kernel])
+                       kernel={"auto": 0, "brute": 1, "bvh": 2, "grid": 3}[a.kernel])
 ctx = rtow.Context(0)
 t0 = time.perf_counter(); ctx.upload(scene); t_up = time.perf_counter() - t0
 out = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")

@@ -37,7 +37,7 @@ def to8(img, spp):
     return (256 * np.clip(np.sqrt(img / spp), 0.0, 0.999)).astype(np.int32)
 
 
-KERNELS = {"stream": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH}
+KERNELS = {"stream": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID}
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
@@ -93,12 +93,13 @@ def test_bvh_and_stream_kernels_agree_bitwise(ctx, name):
     w = 320
     h = rtow.image_height(w, aspect)
     imgs = []
-    for k in (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH):
+    for k in (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_GRID):
         cfg = rtow.make_config(w, h, 8, 2, depth, seed=seed + 100, precision=rtow.F64_STRICT, kernel=k)
         img, st = ctx.render(scene, cfg)
+        assert st.kernel_used == k
         imgs.append((img, st.segments))
-    assert imgs[0][1] == imgs[1][1]
-    assert np.array_equal(imgs[0][0], imgs[1][0])
+    assert imgs[0][1] == imgs[1][1] == imgs[2][1]
+    assert np.array_equal(imgs[0][0], imgs[1][0]) and np.array_equal(imgs[0][0], imgs[2][0])
 
 
 def test_mesh100k_global_image_path_is_bit_identical(ctx, tmp_path):
@@ -192,7 +193,7 @@ def _random_sphere_scene(hollow):
 def test_overlapping_spheres_one_material_each(ctx):
     """43 overlapping spheres, a material per primitive (all three kinds); strict vs oracle."""
     sc, keep = _random_sphere_scene(hollow=False)
-    for kernel in (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH):
+    for kernel in (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_GRID):
         cfg = rtow.make_config(80, 40, 6, 2, 30, seed=9, precision=rtow.F64_STRICT, kernel=kernel)
         img, st = ctx.render(sc, cfg)
         ref, ost = orc.render(sc, cfg, orc.RNG_PHILOX, nthreads=4)
