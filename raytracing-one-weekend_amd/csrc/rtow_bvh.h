@@ -198,7 +198,7 @@ inline void pad_box(Box &b) {
 // sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
 inline void build_bvh(const std::vector<double> &sph, const std::vector<double> &sph_r,
                       const std::vector<double> &mov, const std::vector<double> &tri, HostBvh &out,
-                      int leaf_max = 4, double c_trav = 0.0) {
+                      int leaf_max = 4, double c_trav = 0.0, double time0 = 0.0, double time1 = 1.0) {
   using namespace bvh_detail;
   const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
   const int n = ns + nm + nt;
@@ -217,13 +217,15 @@ inline void build_bvh(const std::vector<double> &sph, const std::vector<double> 
     }
   }
   for (int i = 0; i < nm; ++i) {
-    // centre moves along c0 + time*delta; the shutter interval is [t0,t1] ⊆ [0,1] in the
-    // reference's scenes — bound over [0,1] widened by the same amount again for safety
+    // centre(time) = c0 + time*delta for time in the camera's shutter interval [time0, time1]
+    // (ray times are drawn from it, src/common-model.cpp:165), widened a little
     Box &b = B.pb[ns + i];
     const double *m = &mov[(size_t)i * 8];
     const double r = std::fabs(m[7]);
+    const double w = 1e-6 * (1.0 + std::fabs(time0) + std::fabs(time1));
+    const double ta = std::min(time0, time1) - w, tb = std::max(time0, time1) + w;
     for (int k = 0; k < 3; ++k) {
-      const double a0 = m[k] - 1.0 * m[3 + k], a1 = m[k] + 2.0 * m[3 + k];
+      const double a0 = m[k] + ta * m[3 + k], a1 = m[k] + tb * m[3 + k];
       b.mn[k] = std::min(a0, a1) - r;
       b.mx[k] = std::max(a0, a1) + r;
     }

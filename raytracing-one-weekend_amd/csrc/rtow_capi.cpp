@@ -274,7 +274,7 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   if (const char *e = std::getenv("RTOW_BVH_LEAF")) leaf_max = std::atoi(e);
   double c_trav = 0.0;
   if (const char *e = std::getenv("RTOW_BVH_CT")) c_trav = std::atof(e);
-  rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav);
+  rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
   rtow::SceneImage img;
   rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img);
   if (!rtow::validate_scene_image(img, ns + nm + nt))
@@ -292,7 +292,8 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   if (const char *e = std::getenv("RTOW_GRID_CPP")) cpp = std::atof(e);
   double large_ratio = 4.0;
   if (const char *e = std::getenv("RTOW_GRID_LARGE")) large_ratio = std::atof(e);
-  rtow::build_grid_image(sph, sph_r, mov, tri, s->camera.origin, gimg, cpp, large_ratio);
+  rtow::build_grid_image(sph, sph_r, mov, tri, s->camera.origin, gimg, cpp, large_ratio, s->camera.t0,
+                         s->camera.t1);
   c->have_grid = gimg.ok;
   c->gblob_bytes = 0;
   if (gimg.ok) {

@@ -42,7 +42,7 @@ struct B3 {
 inline void build_grid_image(const std::vector<double> &sph, const std::vector<double> &sph_r,
                              const std::vector<double> &mov, const std::vector<double> &tri,
                              const double cam_origin[3], GridImage &img, double cells_per_prim = 1.5,
-                             double large_ratio = 4.0) {
+                             double large_ratio = 4.0, double time0 = 0.0, double time1 = 1.0) {
   using grid_detail::B3;
   const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
   const int np = ns + nm + nt;
@@ -56,11 +56,13 @@ inline void build_grid_image(const std::vector<double> &sph, const std::vector<d
       pb[i].mx[k] = sph[(size_t)i * 4 + k] + r;
     }
   }
-  for (int i = 0; i < nm; ++i) {  // bound the motion over time in [-1, 2] ⊇ any shutter in [0,1]
+  for (int i = 0; i < nm; ++i) {  // centre(time) over the camera's shutter interval, widened a little
     const double *m = &mov[(size_t)i * 8];
     const double r = std::fabs(m[7]);
+    const double w = 1e-6 * (1.0 + std::fabs(time0) + std::fabs(time1));
+    const double ta = std::min(time0, time1) - w, tb = std::max(time0, time1) + w;
     for (int k = 0; k < 3; ++k) {
-      const double a0 = m[k] - m[3 + k], a1 = m[k] + 2.0 * m[3 + k];
+      const double a0 = m[k] + ta * m[3 + k], a1 = m[k] + tb * m[3 + k];
       pb[ns + i].mn[k] = std::min(a0, a1) - r;
       pb[ns + i].mx[k] = std::max(a0, a1) + r;
     }
