@@ -16,9 +16,10 @@ One JSON line on rank 0, with
   roofline     — SURVEY.md §8d's streaming model: algorithmic bytes per launch =
                  ceil(segments/64) * N_prim * 32 B + W*H*24 B, divided by the trace
                  kernel's mean duration measured with HIP events on the launch
-                 stream inside the timed region; peak = 8 TB/s HBM.  The scene is
-                 cache/SGPR resident, so this is a VALU-bound kernel: roofline_valu
-                 gives the f64 vector-FLOP view next to it.
+                 stream inside the timed region; peak = 8 TB/s HBM; `traffic` = HBM
+                 bytes per launch from the committed PMC passes (profiles/).  The
+                 scene is LDS resident, so the kernel is VALU-bound, not HBM-bound:
+                 `walk` gives what the kernel really reads (LDS) and computes.
   cpu_baseline — oracle/ (the CPU restatement of the reference's sample loop, same
                  Philox stream) timed on this host's cores on a bounded sample of
                  the same workload (same scene and resolution, fewer spp).
@@ -204,13 +205,16 @@ def main():
         fmodel = "segments*N_prim*23 flop (sphere test to the discriminant reject, streaming model)"
         walked = None
         if st0.kernel_used in (rtow.KERNEL_BVH, rtow.KERNEL_GRID):
-            # what the BVH kernel really reads and computes per launch (its own counters): every
-            # lane reads a 32 B node per box test and a 32 B record + 4 B id per primitive test,
-            # all from the LDS scene image
+            # what the walking kernels really read and compute per launch (their own counters),
+            # all from the LDS scene image: BVH = a 32 B node per box test, GRID = a 4 B cell word
+            # per DDA step; both a 32 B record + 4 B id per primitive test
+            grid = st0.kernel_used == rtow.KERNEL_GRID
+            nb, nf = (4, 12) if grid else (BYTES_PER_NODE, FLOPS_PER_BOX_TEST)
             walked = {
-                "lds_bytes_per_launch": int(st0.node_tests) * BYTES_PER_NODE + int(st0.prim_tests) * (BYTES_PER_SPHERE + 4),
-                "flops_per_launch": int(st0.node_tests) * FLOPS_PER_BOX_TEST + int(st0.prim_tests) * FLOPS_PER_SPHERE_TEST,
-                "model": "node_tests*32B + prim_tests*36B ; node_tests*17 flop (f32 slab) + prim_tests*23 flop (f64)",
+                "lds_bytes_per_launch": int(st0.node_tests) * nb + int(st0.prim_tests) * (BYTES_PER_SPHERE + 4),
+                "flops_per_launch": int(st0.node_tests) * nf + int(st0.prim_tests) * FLOPS_PER_SPHERE_TEST,
+                "model": (f"node_tests*{nb}B + prim_tests*36B ; node_tests*{nf} flop (f32 "
+                          + ("DDA step" if grid else "slab") + ") + prim_tests*23 flop (f64)"),
             }
             walked["lds_GBps"] = round(walked["lds_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1)
             walked["TFLOPs"] = round(walked["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12, 3)
@@ -253,7 +257,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "model": model,
             },
-            "bvh_walk": walked,
+            "walk": walked,
             "roofline_valu": None if walked else {
                 "bound": "valu_f64", "achieved": round(alg_flops / (kernel_ms * 1e-3) / 1e12, 3),
                 "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
