@@ -121,7 +121,7 @@ typedef struct rtow_scene_t {
  * run order.  Effective spp = samples_per_pixel / nstreams * nstreams.
  *
  * Random numbers are counter-based: draw d of sample s of pixel p (global
- * row-major index, top row first) is Philox4x32-10 keyed by `seed`; the image
+ * row-major index, top row first) is a Philox4x32-7 block keyed by `seed`; the image
  * therefore does not depend on nranks, tile_rows or on which lane traced what. */
 typedef struct rtow_config_t {
   int32_t image_width;
