@@ -78,12 +78,35 @@ __device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y
 __device__ __forceinline__ V3 cross(V3 x, V3 y) {
   return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
 }
+#ifdef RTOW_FAST_MATH
+// fast build: hardware reciprocal-square-root seed (~2^-26) + two Newton steps instead of the
+// correctly rounded sqrt and division (relative error ~1e-16; the strict build keeps IEEE forms)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x) { return x > 0.0 ? x * fast_rsqrt(x) : 0.0; }
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+__device__ __forceinline__ double fast_div(double n, double d) { return n * fast_rcp(d); }
+__device__ __forceinline__ V3 normalize(V3 v) { return v * fast_rsqrt(dot(v, v)); }
+#else
+__device__ __forceinline__ double fast_div(double n, double d) { return n / d; }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ V3 normalize(V3 v) { return v * (1.0 / sqrt(dot(v, v))); }
+#endif
 __device__ __forceinline__ V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2.0; }
 __device__ __forceinline__ V3 refract(V3 I, V3 N, double eta) {
   double d = dot(N, I);
   double k = 1.0 - eta * eta * (1.0 - d * d);
-  if (k >= 0.0) return eta * I - (eta * d + sqrt(k)) * N;
+  if (k >= 0.0) return eta * I - (eta * d + fast_sqrt(k)) * N;
   return {0.0, 0.0, 0.0};
 }
 __device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
@@ -177,7 +200,7 @@ __device__ __forceinline__ void sphere_test(V3 o, V3 d, double a, double inv_a, 
   double c = dot(oc, oc) - r2;
   double disc = h * h - a * c;
   if (disc >= 0.0) {
-    double sq = sqrt(disc);
+    double sq = fast_sqrt(disc);
 #ifdef RTOW_FAST_MATH
     double root = (-h - sq) * inv_a;
     const double root2 = (-h + sq) * inv_a;
@@ -205,7 +228,7 @@ __device__ __forceinline__ void sphere_test(V3 o, V3 d, double a, double inv_a, 
 __device__ __forceinline__ void triangle_test(V3 o, V3 d, V3 A, V3 e1, V3 e2, V3 n, int id,
                                               double tmin, Closest &best) {
   double det = -dot(d, n);
-  double invdet = 1.0 / det;
+  double invdet = fast_rcp(det);  // strict build: 1.0 / det
   V3 ao = o - A;
   V3 dao = cross(ao, d);
   double u = dot(e2, dao) * invdet;
@@ -226,7 +249,7 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, 
   best.prim = -1;
   const double tmin = RTOW_TMIN;
   const double a = dot(d, d);
-  const double inv_a = 1.0 / a;
+  const double inv_a = fast_rcp(a);  // used by the fast build only
   {
     cdptr g = (cdptr)sc.sph;
     const int n = sc.n_sph;
@@ -372,7 +395,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   best.t = __builtin_huge_val();
   best.prim = -1;
   const double a = dot(d, d);
-  const double inv_a = 1.0 / a;
+  const double inv_a = fast_rcp(a);  // used by the fast build only
   // f32 copy of the ray for the (conservative) box tests
   const float ix = safe_inv((float)d.x), iy = safe_inv((float)d.y), iz = safe_inv((float)d.z);
   const float oix = (float)o.x * ix, oiy = (float)o.y * iy, oiz = (float)o.z * iz;
@@ -440,7 +463,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   best.t = __builtin_huge_val();
   best.prim = -1;
   const double a = dot(d, d);
-  const double inv_a = 1.0 / a;
+  const double inv_a = fast_rcp(a);  // used by the fast build only
   const ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri};
   int last_id = -1;
   // header: wave-uniform scalar loads from the global copy of the image
@@ -656,8 +679,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       const int from_top_i = P.H - (int)gi - 1;
       double ju, jv, jt;
       rng_jitter(g, k0, k1, ju, jv, jt);
-      const double u = ((double)(int)j + ju) / (double)(P.W - 1);
-      const double v = ((double)from_top_i + jv) / (double)(P.H - 1);
+      const double u = fast_div((double)(int)j + ju, (double)(P.W - 1));
+      const double v = fast_div((double)from_top_i + jv, (double)(P.H - 1));
       // src/common-model.cpp:156-167; disk sample: y draws first (random-utils.cpp:36)
       double px, py;
       for (;;) {
@@ -741,11 +764,11 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             const double ir = m->ir;
             const V3 unit = normalize(rd);
             const double cos_theta = dot(-unit, normal);
-            const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-            const double ratio = front ? (1.0 / ir) : ir;
+            const double sin_theta = fast_sqrt(1.0 - cos_theta * cos_theta);
+            const double ratio = front ? fast_rcp(ir) : ir;
             bool refl = ratio * sin_theta > 1.0;
             if (!refl) {
-              double r0 = (1.0 - ratio) / (1.0 + ratio);
+              double r0 = fast_div(1.0 - ratio, 1.0 + ratio);
               r0 = r0 * r0;
               const double x = 1.0 - cos_theta;
               const double x2 = x * x;
