@@ -161,3 +161,28 @@ def test_philox_and_mt_images_agree_statistically():
     b, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=4)
     ma, mb = a.mean(axis=(0, 1)) / 16, b.mean(axis=(0, 1)) / 16
     assert np.all(np.abs(ma - mb) < 0.01), (ma, mb)
+
+
+def test_t3_philox_vs_mt19937_rmse_against_two_independent_mt_runs():
+    """the counter-based stream against the reference's stream — RMSE <= 1.5x
+    the RMSE between two INDEPENDENT mt19937 renders (the second one made independent by burning
+    draws before render), and channel means within Monte-Carlo noise.  The device path is
+    bit-identical to the Philox oracle (GPU tests), so this carries over to it."""
+    spp, W, H = 32, 72, 48
+
+    def to8(img):
+        return 256 * np.clip(np.sqrt(img / spp), 0.0, 0.999)
+
+    cfg = rtow.make_config(W, H, spp, 1, 50, seed=31)
+    s0 = orc.OrcScene.cover(11, 1.5, False)
+    a, _ = orc.render(s0, cfg, orc.RNG_MT19937)
+    s1 = orc.OrcScene.cover(11, 1.5, False)        # same scene (generator reset) ...
+    orc.lib().orc_mt_burn(12345)                   # ... different render stream
+    b, _ = orc.render(s1, cfg, orc.RNG_MT19937)
+    c, _ = orc.render(s0, cfg, orc.RNG_PHILOX, nthreads=4)
+    assert np.array_equal(orc.scene_arrays(s0.c)["sphere_geom"], orc.scene_arrays(s1.c)["sphere_geom"])
+    rmse_ref = np.sqrt(np.mean((to8(a) - to8(b)) ** 2))
+    rmse_phi = np.sqrt(np.mean((to8(a) - to8(c)) ** 2))
+    assert rmse_phi <= 1.5 * rmse_ref, (rmse_phi, rmse_ref)
+    # means: the Monte-Carlo noise of an image mean at this size is ~0.3/255; allow 1/255
+    assert np.all(np.abs(to8(a).mean(axis=(0, 1)) - to8(c).mean(axis=(0, 1))) < 1.0)
