@@ -461,7 +461,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   const size_t depth_slots = (size_t)(cfg->max_child_rays > 0 ? cfg->max_child_rays : 1);
   if ((rc = c->partials.ensure((size_t)n_items * 3 * sizeof(double))) ||
       (rc = c->stack.ensure(depth_slots * (size_t)n_lanes * sizeof(uint32_t))) ||
-      (rc = c->counters.ensure(16 * sizeof(unsigned long long))))
+      (rc = c->counters.ensure(24 * sizeof(unsigned long long))))
     return rc;
 
   rtow::TraceParams P;
@@ -503,9 +503,12 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
   P.counters = (unsigned long long *)c->counters.p;
+  P.t_origin = P.counters + 16;
 
   if (stats) HIPCHK(hipEventRecord(c->call_ev[0], st));
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, 16 * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, 24 * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 5, 0xff, sizeof(unsigned long long), st));   // min end
+  HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 16, 0xff, sizeof(unsigned long long), st));  // t_origin
   const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
   if (slot >= 0) HIPCHK(hipEventRecord(c->ev[slot][0], st));
   int launch_kernel = kernel;

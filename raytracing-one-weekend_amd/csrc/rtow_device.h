@@ -80,6 +80,7 @@ struct TraceParams {
   double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests
+  unsigned long long *t_origin; // diagnostic build: earliest wave start (100 MHz clock)
 };
 
 struct ReduceParams {

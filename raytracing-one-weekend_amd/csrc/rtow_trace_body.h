@@ -599,8 +599,14 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   Rng g = {0, 0, 0};
   uint32_t nseg = 0, nnode = 0, nprim = 0;
   uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: this wave's batch of work items
+  unsigned long long seen = 0ull;        // wave-uniform: queue head as of this wave's last fetch
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   Stamps<STAMPS> stamps;
   stamps.start();
+  unsigned long long t_empty = 0ull;  // diagnostic: when this wave first saw the queue empty
+  if constexpr (STAMPS) {
+    if (lane == 0) atomicMin(P.t_origin, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
 
   for (;;) {
     // ---- item bookkeeping ---------------------------------------------------
@@ -625,12 +631,20 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
       unsigned long long mine = (unsigned long long)pool_next + rank;
       if (want > avail) {
+        // guided self-scheduling: 64 items per atomic while the queue is long, shrinking to
+        // exactly what this wave needs now as it drains (a wave that hoards items at the end
+        // of the queue keeps the whole launch waiting: measured ~4 item durations per launch)
+        const unsigned long long left = (unsigned long long)P.n_items > seen ? (unsigned long long)P.n_items - seen : 0ull;
+        uint32_t batch = (uint32_t)(left / ((unsigned long long)n_waves * 4ull));
+        batch = batch > kItemBatch ? kItemBatch : batch;
+        batch = batch < want - avail ? want - avail : batch;
         const int leader = __ffsll((long long)need_mask) - 1;
         unsigned long long base = 0ull;
-        if ((int)lane == leader) base = atomicAdd(&P.counters[0], (unsigned long long)kItemBatch);
+        if ((int)lane == leader) base = atomicAdd(&P.counters[0], (unsigned long long)batch);
         base = __shfl(base, leader);
+        seen = base + batch;  // how far the queue had advanced when this wave last looked
         if (rank >= avail) mine = base + (rank - avail);
-        const unsigned long long nn = base + (want - avail), ne = base + kItemBatch;
+        const unsigned long long nn = base + (want - avail), ne = base + batch;
         const unsigned long long cap = (unsigned long long)P.n_items;
         pool_next = (uint32_t)(nn < cap ? nn : cap);
         pool_end = (uint32_t)(ne < cap ? ne : cap);
@@ -640,8 +654,13 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       if (need_item) {
         if (mine >= (unsigned long long)P.n_items) {
           done = true;
+          if constexpr (STAMPS) {
+            if (t_empty == 0ull) t_empty = __builtin_amdgcn_s_memrealtime();
+          }
         } else {
-          item = (uint32_t)mine;
+          // the queue is consumed from its far end: within a stream tiles run bottom-to-top, so
+          // a launch ends on the (typically cheap) top of the image, not on its most expensive tiles
+          item = P.n_items - 1u - (uint32_t)mine;
           const uint32_t k = fastdiv(item, P.div_npix);  // stream
           const uint32_t lp = item - k * npix_local;     // local pixel
           uint32_t lr;
@@ -826,6 +845,14 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   if constexpr (STAMPS) {
     if (lane == 0)
     {
+      // wave lifetime on the 100 MHz constant clock: [4] sum of end times, [5] min, [6] max,
+      // [7] sum of the times at which the wave first found the queue empty (relative to the
+      // earliest start, kept in [8+RG_COUNT+3] as a min)
+      const unsigned long long tend = __builtin_amdgcn_s_memrealtime();
+      atomicAdd(&P.counters[4], tend - P.t_origin[0]);
+      atomicMin(&P.counters[5], tend - P.t_origin[0]);
+      atomicMax(&P.counters[6], tend - P.t_origin[0]);
+      atomicAdd(&P.counters[7], t_empty - P.t_origin[0]);
       for (int r = 0; r < RG_COUNT; ++r) atomicAdd(&P.counters[8 + r], stamps.t[r]);
       atomicAdd(&P.counters[13], stamps.iters);
       atomicAdd(&P.counters[14], stamps.trips);

@@ -12,7 +12,7 @@ if which == "suzanne":
     cfg = rtow.make_config(1920, 1080, 16, 2, 20, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
 else:
     scene = rtow.HostScene.cover(11, 1.5, which == "moving")
-    cfg = rtow.make_config(1200, 800, 100, 10, 50, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
+    cfg = rtow.make_config(1200, 800, 100, int(os.environ.get('RTOW_NSTREAMS', '10')), 50, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
 ctx = rtow.Context(0)
 img, st = ctx.render(scene, cfg)
 out = (C.c_ulonglong * 16)()
@@ -27,3 +27,5 @@ for i, n in enumerate(names):
 iters, trips, phases = out[13], out[14], out[15]
 print(f"wave trips {trips}, step-loop iterations per trip {iters/max(trips,1):.1f}, leaf phases per trip {phases/max(trips,1):.2f}, "
       f"lane-segments per trip {st.segments/max(trips,1):.1f} of 64")
+nw = 4096.0
+print(f"wave end times (ms after first wave start): mean {out[4]/nw/1e5:.3f}  min {out[5]/1e5:.3f}  max {out[6]/1e5:.3f};  queue seen empty (mean over waves) {out[7]/nw/1e5:.3f}")
