@@ -406,7 +406,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri};
   int last_id = -1;
   uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
-  uint32_t q0 = 0u, q1 = 0u;  // queued leaves (0 = empty)
+  uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u;  // queued leaves (0 = empty), oldest first
   // Termination: every link of the image points forward (node+1 or skip > node, checked
   // by the host at upload) and the walk stops at any index >= END, so a lane takes at
   // most n_nodes steps.  (A per-trip guard counter here cost 7 % of the kernel.)
@@ -425,20 +425,26 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
       if (hit && leaf != 0u) {
         if (q0 == 0u)
           q0 = leaf;
-        else
+        else if (q1 == 0u)
           q1 = leaf;
+        else if (q2 == 0u)
+          q2 = leaf;
+        else
+          q3 = leaf;
       }
       node = (hit && leaf == 0u) ? node + 1u : skip;
     }
     const bool any_walking = __any(node < END);
-    if (__any(q1 != 0u) || !any_walking) {
+    if (__any(q3 != 0u) || !any_walking) {
       stamps.mark(RG_WALK);
       if constexpr (ST) stamps.phases += 1;
       // leaf phase: every lane tests the primitives of the OLDEST leaf it queued (most
       // lanes hold one; only the lanes whose queue filled hold two, and theirs moves up)
       if (q0 != 0u) leaf_test(im, sc, off, q0 >> 3, q0 & 7u, o, d, a, inv_a, time, best, nprim, last_id);
       q0 = q1;
-      q1 = 0u;
+      q1 = q2;
+      q2 = q3;
+      q3 = 0u;
       // shrink the f32 interval (rounded up: never below the f64 value)
       tmax32 = __double2float_ru(best.t);
       stamps.mark(RG_LEAF);
