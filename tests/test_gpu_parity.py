@@ -219,6 +219,34 @@ def test_negative_radius_hollow_sphere(ctx):
     assert not np.array_equal(imgs[0], other) and np.isfinite(imgs[0]).all()
 
 
+def test_context_reuse_across_scenes_and_shapes(ctx):
+    """One context, several uploads and render shapes in a row (workspace regrowth, kernel
+    switches STREAM/GRID/BVH, LDS and global scene images) — every result still bit-identical."""
+    scenes = [
+        (rtow.HostScene.cover(0, 1.5, False), 10, rtow.KERNEL_BRUTE),     # 4 primitives -> STREAM
+        (rtow.HostScene.cover(11, 1.5, True), 50, rtow.KERNEL_GRID),      # spheres -> GRID
+        (rtow.HostScene.obj(GOLDEN / "suzanne.obj", 1.5), 20, rtow.KERNEL_BVH),  # mesh -> BVH
+        (rtow.HostScene.cover(5, 1.5, False), 30, rtow.KERNEL_GRID),
+    ]
+    for (scene, depth, expect), (w, h, spp, ns) in zip(scenes, [(64, 40, 6, 3), (31, 17, 5, 1), (96, 64, 4, 2),
+                                                                (200, 120, 2, 2)]):
+        cfg = rtow.make_config(w, h, spp, ns, depth, seed=w, precision=rtow.F64_STRICT)
+        img, st = ctx.render(scene, cfg)
+        assert st.kernel_used == expect
+        ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+        assert st.segments == ost.segments and np.array_equal(img, ref)
+
+
+def test_degenerate_image_shapes(ctx):
+    scene = rtow.HostScene.cover(3, 1.5, False)
+    for w, h in ((2, 2), (64, 1), (1, 5), (65, 3)):   # W-1 or H-1 may be 0: the reference divides by them too
+        cfg = rtow.make_config(w, h, 3, 1, 8, seed=5, precision=rtow.F64_STRICT)
+        img, st = ctx.render(scene, cfg)
+        ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX)
+        assert img.shape == (h, w, 3)
+        assert np.array_equal(img, ref, equal_nan=True)
+
+
 def test_image_does_not_depend_on_the_partition(ctx):
     scene = rtow.HostScene.cover(11, 1.5, True)
     W, H = 50, 37
