@@ -177,6 +177,13 @@ int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t cap
 int rtow_render_device(rtow_ctx *ctx, const rtow_config_t *cfg, void *d_rgb_sums,
                        void *hip_stream, rtow_stats_t *stats);
 
+/* write_color on the device (reference src/render.cpp:11-20): for each of the n_values
+ * doubles of `d_rgb_sums`, byte = int(256 * clamp(sqrt(sum / spp_effective), 0, 0.999)) into
+ * `d_rgb8` (device pointer, n_values bytes).  Enqueued on `hip_stream`, no sync.  The bytes
+ * equal the numbers the reference prints in its P3 file. */
+int rtow_tonemap_device(rtow_ctx *ctx, const void *d_rgb_sums, int64_t n_values, int32_t spp_effective,
+                        void *d_rgb8, void *hip_stream);
+
 /* Every rtow_render_device call brackets its trace-kernel launch with a HIP event
  * pair on the launch stream (no host sync).  This collects the device time of
  * all launches since the previous collect (it waits for them) and resets the
@@ -192,6 +199,11 @@ int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out16);
 /* Convenience: upload + render + copy this rank's rows to host memory. */
 int rtow_render(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,
                 double *rgb_sums_host, rtow_stats_t *stats);
+
+/* Convenience: upload + render + write_color on the device + copy this rank's rows as 8-bit
+ * RGB (rows*W*3 bytes) to host memory — the payload of a binary P6 PPM. */
+int rtow_render_rgb8(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,
+                     unsigned char *rgb8_host, rtow_stats_t *stats);
 
 /* ---- host-side scene construction (no GPU needed) --------------------------
  * C entry points over the C++ mirror of the reference's scene-build API

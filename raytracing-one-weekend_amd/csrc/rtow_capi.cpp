@@ -568,6 +568,20 @@ int rtow_debug_counters(rtow_ctx *c, unsigned long long *out16) {
   return RTOW_OK;
 }
 
+// write_color as a device epilogue: 8-bit RGB from the radiance sums.
+int rtow_tonemap_device(rtow_ctx *c, const void *d_rgb_sums, int64_t n_values, int32_t spp_effective,
+                        void *d_rgb8, void *hip_stream) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  if (!d_rgb_sums || !d_rgb8) return fail(RTOW_EINVAL, "NULL device pointer");
+  if (n_values < 0 || n_values > 0xffffffffLL) return fail(RTOW_EINVAL, "n_values out of range");
+  if (spp_effective <= 0) return fail(RTOW_EINVAL, "spp_effective must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  int lrc = rtow::launch_tonemap((const double *)d_rgb_sums, (unsigned char *)d_rgb8, (uint32_t)n_values,
+                                 (double)spp_effective, hip_stream);
+  if (lrc != 0) return fail(RTOW_EHIP, "tonemap launch failed: %s", hipGetErrorString((hipError_t)lrc));
+  return RTOW_OK;
+}
+
 int rtow_profile_collect(rtow_ctx *c, double *kernel_ms_sum, int32_t *launches) {
   if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
@@ -608,6 +622,42 @@ int rtow_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg
     if (e != hipSuccess) rc = fail(RTOW_EHIP, "D2H copy failed: %s", hipGetErrorString(e));
   }
   (void)hipFree(d_out);
+  return rc;
+}
+
+// upload + render + device write_color + copy 8-bit RGB to the host: the whole output path of
+// the reference's render() with 3 bytes per pixel over PCIe instead of 24.
+int rtow_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, unsigned char *rgb8_host,
+                     rtow_stats_t *stats) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  if (!rgb8_host) return fail(RTOW_EINVAL, "rgb8_host is NULL");
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  const int spp_eff = cfg->samples_per_pixel / cfg->nstreams * cfg->nstreams;  // src/render.cpp:185
+  if (spp_eff <= 0) return fail(RTOW_EINVAL, "no effective samples (samples_per_pixel < nstreams)");
+  if ((rc = rtow_scene_upload(c, scene))) return rc;
+  const int rows = rtow_local_rows(cfg);
+  const size_t n = (size_t)rows * cfg->image_width * 3;
+  rtow_stats_t local;
+  if (n == 0) {
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    return RTOW_OK;
+  }
+  void *d_sums = nullptr, *d_rgb8 = nullptr;
+  HIPCHK(hipMalloc(&d_sums, n * sizeof(double)));
+  hipError_t e = hipMalloc(&d_rgb8, n);
+  if (e != hipSuccess) {
+    (void)hipFree(d_sums);
+    return fail(RTOW_EHIP, "hipMalloc: %s", hipGetErrorString(e));
+  }
+  rc = rtow_render_device(c, cfg, d_sums, nullptr, stats ? stats : &local);
+  if (rc == RTOW_OK) rc = rtow_tonemap_device(c, d_sums, (int64_t)n, spp_eff, d_rgb8, nullptr);
+  if (rc == RTOW_OK) {
+    e = hipMemcpy(rgb8_host, d_rgb8, n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(RTOW_EHIP, "D2H copy failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_sums);
+  (void)hipFree(d_rgb8);
   return rc;
 }
 

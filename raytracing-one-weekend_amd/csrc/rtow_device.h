@@ -101,5 +101,6 @@ int launch_trace_fast(const TraceParams &p, int kernel, int grid, int block, uns
 int trace_occupancy_strict(int kernel, int block, unsigned lds_bytes);
 int trace_occupancy_fast(int kernel, int block, unsigned lds_bytes);
 int launch_reduce(const ReduceParams &p, void *stream);
+int launch_tonemap(const double *sums, unsigned char *rgb8, uint32_t n, double spp, void *stream);
 
 }  // namespace rtow

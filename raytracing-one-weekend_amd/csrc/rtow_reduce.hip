@@ -23,7 +23,26 @@ __global__ void __launch_bounds__(256) rtow_reduce_streams(const ReduceParams p)
   for (int k = 0; k < p.nstreams; ++k) g = p.partials[(size_t)k * p.npix3 + src] + g;
   p.out[idx] = g;
 }
+// write_color on the device (src/render.cpp:11-20): c = sqrt(sum / spp), clamp to [0, 0.999],
+// int(256 * c) — one byte per channel.  f64 sqrt and division are the correctly rounded IEEE
+// forms and this file is built with -ffp-contract=off, so the bytes equal the reference's.
+__global__ void __launch_bounds__(256) rtow_tonemap_u8(const double *sums, unsigned char *rgb8, uint32_t n,
+                                                       double spp) {
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= n) return;
+  double c = sqrt(sums[idx] / spp);
+  c = c < 0.0 ? 0.0 : (c > 0.999 ? 0.999 : c);  // std::clamp(c, 0.0, 0.999); NaN stays NaN -> 0 below
+  const int v = (int)(256.0 * c);
+  rgb8[idx] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
 }  // namespace
+
+int launch_tonemap(const double *sums, unsigned char *rgb8, uint32_t n, double spp, void *stream) {
+  const unsigned grid = (n + 255u) / 256u;
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL(rtow_tonemap_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream, sums, rgb8, n, spp);
+  return (int)hipGetLastError();
+}
 
 int launch_reduce(const ReduceParams &p, void *stream) {
   const unsigned grid = (p.npix3 + 255u) / 256u;

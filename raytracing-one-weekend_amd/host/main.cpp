@@ -30,7 +30,8 @@ static void usage(const char *argv0) {
                "  --device INT                HIP device index (default 0)\n"
                "  --seed UINT                 render seed of the counter-based RNG (default 1)\n"
                "  --precision strict|fast     f64 without / with FMA contraction (default fast)\n"
-               "  --kernel auto|brute|bvh     closest-hit strategy (default auto)\n";
+               "  --kernel auto|brute|bvh|grid  closest-hit strategy (default auto)\n"
+               "  --p6                        binary P6 output, write_color on the device\n";
 }
 
 int main(int argc, char *argv[]) {
@@ -80,12 +81,15 @@ int main(int argc, char *argv[]) {
         if (v == "strict") opt.precision = 0;
         else if (v == "fast") opt.precision = 1;
         else throw std::runtime_error("--precision: strict|fast");
+      } else if (std::strcmp(a, "--p6") == 0) {
+        opt.binary_ppm = true;
       } else if (std::strcmp(a, "--kernel") == 0) {
         const std::string v = value();
         if (v == "auto") opt.kernel = 0;
         else if (v == "brute") opt.kernel = 1;
         else if (v == "bvh") opt.kernel = 2;
-        else throw std::runtime_error("--kernel: auto|brute|bvh");
+        else if (v == "grid") opt.kernel = 3;
+        else throw std::runtime_error("--kernel: auto|brute|bvh|grid");
       } else {
         throw std::runtime_error(std::string("The following argument was not expected: ") + a);
       }

@@ -216,18 +216,27 @@ void render(const Scene &world, const Config &cfg) {
   rc.tile_rows = 8;
   rc.seed = opt.seed;
 
-  std::vector<double> image((size_t)cfg.image_width * (image_height > 0 ? image_height : 0) * 3);
+  const size_t nvalues = (size_t)cfg.image_width * (image_height > 0 ? image_height : 0) * 3;
+  std::vector<double> image(opt.binary_ppm ? 0 : nvalues);
+  std::vector<unsigned char> rgb8(opt.binary_ppm ? nvalues : 0);
   rtow_ctx *ctx = nullptr;
   rtow_stats_t st;
   int err = rtow_ctx_create(opt.device, &ctx);
-  if (err == RTOW_OK) err = rtow_render(ctx, flat_view(flat), &rc, image.data(), &st);
+  if (err == RTOW_OK)
+    err = opt.binary_ppm ? rtow_render_rgb8(ctx, flat_view(flat), &rc, rgb8.data(), &st)
+                         : rtow_render(ctx, flat_view(flat), &rc, image.data(), &st);
   std::string msg = err == RTOW_OK ? "" : rtow_last_error();
   rtow_ctx_destroy(ctx);
   flat_free(flat);
   if (err != RTOW_OK) throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + msg);
 
   const int spp_eff = cfg.samples_per_pixel / cfg.nthreads * cfg.nthreads;  // src/render.cpp:185
-  std::cout << ppm_text(image.data(), cfg.image_width, image_height, spp_eff);
+  if (opt.binary_ppm) {
+    std::cout << "P6\n" << cfg.image_width << ' ' << image_height << "\n255\n";
+    std::cout.write(reinterpret_cast<const char *>(rgb8.data()), (std::streamsize)rgb8.size());
+  } else {
+    std::cout << ppm_text(image.data(), cfg.image_width, image_height, spp_eff);
+  }
 
   auto took = khr::high_resolution_clock::now() - start;
   std::cerr << "Traced " << st.samples << " samples, " << st.segments << " ray segments; kernel "

@@ -86,7 +86,8 @@ EXPORTS = [
     "rtow_abi_version", "rtow_last_error", "rtow_ctx_create", "rtow_ctx_destroy",
     "rtow_scene_upload", "rtow_local_rows", "rtow_local_row_list", "rtow_render_device",
     "rtow_render", "rtow_host_scene_cover", "rtow_host_scene_obj", "rtow_host_scene_free",
-    "rtow_host_rng_reset", "rtow_host_ppm", "rtow_host_free",
+    "rtow_host_rng_reset", "rtow_host_ppm", "rtow_host_free", "rtow_tonemap_device",
+    "rtow_profile_collect", "rtow_debug_counters", "rtow_render_rgb8",
 ]
 
 
@@ -128,6 +129,7 @@ def lib():
                                 C.POINTER(C.c_uint64)]
     L.rtow_host_free.argtypes = [C.c_void_p]
     L.rtow_host_free.restype = None
+    L.rtow_tonemap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     if L.rtow_abi_version() != RTOW_ABI_VERSION:
         raise RtowError("librtow.so ABI version mismatch")
     _lib = L
@@ -246,6 +248,11 @@ class Context:
                                        C.c_void_p(stream), C.byref(st) if st is not None else None),
               "rtow_render_device")
         return st
+
+    def tonemap_device(self, d_sums: int, n_values: int, spp_eff: int, d_rgb8: int, stream: int = 0):
+        """write_color on the device: 8-bit RGB from radiance sums (both device pointers)."""
+        check(lib().rtow_tonemap_device(self._h, C.c_void_p(d_sums), n_values, spp_eff,
+                                        C.c_void_p(d_rgb8), C.c_void_p(stream)), "rtow_tonemap_device")
 
     def render(self, scene, cfg: Config):
         """Upload + render + D2H: returns (numpy [rows, W, 3] float64 sums, Stats)."""

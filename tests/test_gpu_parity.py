@@ -154,6 +154,13 @@ def test_rtweekend_binary_ppm_is_byte_identical_to_oracle(ctx):
     ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=4)
     assert r.stdout == orc.ppm_text(ref, 64, 36, 4)
     assert b"Scene has 968 triangles" in r.stderr
+    # --p6: binary PPM, write_color on the device: same numbers as the P3 text
+    r6 = subprocess.run([str(exe), "-l", str(GOLDEN / "suzanne.obj"), "-w", "64", "-a", str(16 / 9), "-s", "4",
+                         "-t", "2", "-c", "20", "--seed", "5", "--precision", "strict", "--p6"],
+                        capture_output=True, check=True)
+    head = b"P6\n64 36\n255\n"
+    assert r6.stdout.startswith(head) and len(r6.stdout) == len(head) + 64 * 36 * 3
+    assert list(r6.stdout[len(head):]) == [int(x) for x in r.stdout.split()[4:]]
 
 
 def _random_sphere_scene(hollow):
@@ -245,6 +252,28 @@ def test_degenerate_image_shapes(ctx):
         ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX)
         assert img.shape == (h, w, 3)
         assert np.array_equal(img, ref, equal_nan=True)
+
+
+def test_device_tonemap_equals_reference_write_color(ctx):
+    """write_color as a device epilogue; bytes == the ints of the oracle's P3."""
+    import torch
+
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    W, H, spp = 120, 80, 12
+    cfg = rtow.make_config(W, H, spp, 3, 50, seed=6, precision=rtow.F64_STRICT)
+    sums = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+    rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    ctx.upload(scene)
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.render_device(cfg, sums.data_ptr(), st, True)
+    # poke the clamp edges too
+    sums[0, 0] = torch.tensor([0.0, 1e9, spp * 0.999**2], dtype=torch.float64)
+    ctx.tonemap_device(sums.data_ptr(), sums.numel(), spp, rgb8.data_ptr(), st)
+    torch.cuda.synchronize()
+    txt = orc.ppm_text(sums.cpu().numpy(), W, H, spp)
+    want = np.array(txt.split()[4:], dtype=np.int64).reshape(H, W, 3)
+    assert np.array_equal(rgb8.cpu().numpy().astype(np.int64), want)
+    assert tuple(want[0, 0]) == (0, 255, 255)
 
 
 def test_image_does_not_depend_on_the_partition(ctx):
