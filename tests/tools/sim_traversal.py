@@ -8,7 +8,7 @@ trip, a lane walks its pixel's samples), and counts, per wave trip:
   packet   : wave-uniform BVH descent — a node is entered when ANY lane's slab test
              passes (node data is wave-uniform → scalar loads, no divergence)
   per-lane : every lane walks the BVH itself; SIMT cost = max over lanes
-Not part of the product or the tests; it only informs DESIGN.md.
+Test-side tooling (it uses the oracle, so it lives under tests/); it only informs DESIGN.md.
 """
 import ctypes as C
 import sys
@@ -16,7 +16,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 sys.path.insert(0, str(ROOT / "raytracing-one-weekend_amd"))
 import orc  # noqa: E402
