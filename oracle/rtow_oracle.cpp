@@ -813,7 +813,7 @@ extern "C" {
 
 void orc_mt_reset(void) { the_generator().seed(5489u); }
 
-// Ray log for offline experiments (scripts/sim_*.py); pass NULL to switch it off.
+// Ray log for offline experiments (tests/tools/sim_traversal.py); pass NULL to switch it off.
 void orc_set_raylog(double *buf, uint64_t capacity_records) {
   g_raylog = buf;
   g_raylog_cap = capacity_records;

@@ -56,7 +56,7 @@ void orc_free(void *p);
 
 /* Optional log of every traced segment (12 doubles each: pixel, sample, segment,
  * origin xyz, direction xyz, time, t_hit or inf, class index of the hit primitive);
- * single-threaded Philox renders only.  Used by scripts/sim_traversal.py. */
+ * single-threaded Philox renders only.  Used by tests/tools/sim_traversal.py. */
 void orc_set_raylog(double *buf, uint64_t capacity_records);
 uint64_t orc_raylog_count(void);
 

@@ -1,4 +1,5 @@
-"""Kernel time vs samples per pixel at a fixed samples-per-item (env SPI): fits the per-launch\nfixed cost (end-of-launch tail) and the steady-state rate.  DESIGN.md, End-of-launch tail."""
+"""Kernel time vs samples per pixel at a fixed samples-per-item (env SPI): fits the per-launch
+fixed cost (end-of-launch tail) and the steady-state rate.  DESIGN.md, End-of-launch tail."""
 import sys, os
 sys.path.insert(0, "raytracing-one-weekend_amd")
 import rtow, torch
