@@ -257,12 +257,15 @@ inline void build_bvh(const std::vector<double> &sph, const std::vector<double> 
 struct SceneImage {
   std::vector<unsigned char> blob;
   uint32_t off_ids = 0, off_sph = 0, off_mov = 0, off_tri = 0;
+  uint32_t off_pmat = 0, off_mats = 0;  // material index per primitive, material records
   int32_t n_nodes = 0;
 };
 
 inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
                              const std::vector<double> &mov, const std::vector<double> &tri,
-                             const double cam_origin[3], SceneImage &img) {
+                             const double cam_origin[3], SceneImage &img,
+                             const std::vector<int32_t> &prim_mat = {},
+                             const std::vector<unsigned char> &mats_bytes = {}) {
   const int n = (int)(bvh.link.size() / 4);
   // the f32 slab test sees the ray origin and the planes rounded to f32: pad every box by
   // more than that rounding can move a plane or an origin anywhere in the scene
@@ -318,8 +321,12 @@ inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
   img.off_sph = (uint32_t)(nodes_bytes + ids_bytes);
   img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
   img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
-  const size_t total = (size_t)img.off_tri + tri.size() * 8;
+  img.off_pmat = (uint32_t)((((size_t)img.off_tri + tri.size() * 8) + 15) / 16 * 16);
+  img.off_mats = (uint32_t)((((size_t)img.off_pmat + prim_mat.size() * 4) + 15) / 16 * 16);
+  const size_t total = (size_t)img.off_mats + mats_bytes.size();
   img.blob.assign(((total + 15) / 16) * 16, 0);
+  if (!prim_mat.empty()) std::memcpy(img.blob.data() + img.off_pmat, prim_mat.data(), prim_mat.size() * 4);
+  if (!mats_bytes.empty()) std::memcpy(img.blob.data() + img.off_mats, mats_bytes.data(), mats_bytes.size());
   img.n_nodes = n;
   for (int i = 0; i < n; ++i) {
     const int nd = order[i];

@@ -220,7 +220,9 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     sph[4 * (size_t)i + 0] = g[0];
     sph[4 * (size_t)i + 1] = g[1];
     sph[4 * (size_t)i + 2] = g[2];
-    sph[4 * (size_t)i + 3] = g[3] * g[3];  // radius * radius, src/common-model.cpp:73
+    // radius * radius (src/common-model.cpp:73), carrying the radius' sign: the tests take |.|
+    // for free (VOP3 input modifier), the shading step reads the sign (front_facing, :88)
+    sph[4 * (size_t)i + 3] = std::copysign(g[3] * g[3], g[3]);
     sph_r[i] = g[3];
   }
   for (int i = 0; i < nm; ++i) {
@@ -232,7 +234,7 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     d[3] = g[3] - g[0];  // center1 - center0, src/oo-primitives.h:65
     d[4] = g[4] - g[1];
     d[5] = g[5] - g[2];
-    d[6] = g[6] * g[6];
+    d[6] = std::copysign(g[6] * g[6], g[6]);
     d[7] = g[6];
   }
   for (int i = 0; i < nt; ++i) {
@@ -276,7 +278,9 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   if (const char *e = std::getenv("RTOW_BVH_CT")) c_trav = std::atof(e);
   rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
   rtow::SceneImage img;
-  rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img);
+  std::vector<unsigned char> mats_bytes(mats.size() * sizeof(rtow::DevMaterial));
+  std::memcpy(mats_bytes.data(), mats.data(), mats_bytes.size());
+  rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img, pmat, mats_bytes);
   if (!rtow::validate_scene_image(img, ns + nm + nt))
     return fail(RTOW_EINVAL, "internal error: scene image failed validation (BVH links)");
 
@@ -293,7 +297,7 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   double large_ratio = 4.0;
   if (const char *e = std::getenv("RTOW_GRID_LARGE")) large_ratio = std::atof(e);
   rtow::build_grid_image(sph, sph_r, mov, tri, s->camera.origin, gimg, cpp, large_ratio, s->camera.t0,
-                         s->camera.t1);
+                         s->camera.t1, pmat, mats_bytes);
   c->have_grid = gimg.ok;
   c->gblob_bytes = 0;
   if (gimg.ok) {
@@ -319,6 +323,8 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   ds.off_sph = img.off_sph;
   ds.off_mov = img.off_mov;
   ds.off_tri = img.off_tri;
+  ds.off_pmat = img.off_pmat;
+  ds.off_mats = img.off_mats;
   ds.n_nodes = img.n_nodes;
   ds.gblob = (const unsigned char *)c->gblob.p;
   ds.gblob_bytes = c->gblob_bytes;
@@ -327,6 +333,8 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   ds.g_off_sph = gimg.off_sph;
   ds.g_off_mov = gimg.off_mov;
   ds.g_off_tri = gimg.off_tri;
+  ds.g_off_pmat = gimg.off_pmat;
+  ds.g_off_mats = gimg.off_mats;
   c->n_prims = ns + nm + nt;
 
   const rtow_camera_t &k = s->camera;

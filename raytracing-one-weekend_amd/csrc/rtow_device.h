@@ -31,9 +31,9 @@ struct DevCamera {         // src/common-model.h:104-112
 
 // class-major global primitive id: [0,n_sph) spheres, then moving, then triangles
 struct DevScene {
-  const double *sph;       // [n_sph][4]  cx cy cz r*r
+  const double *sph;       // [n_sph][4]  cx cy cz copysign(r*r, r)
   const double *sph_r;     // [n_sph]     r (sign decides front_facing)
-  const double *mov;       // [n_mov][8]  c0xyz (c1-c0)xyz r*r r
+  const double *mov;       // [n_mov][8]  c0xyz (c1-c0)xyz copysign(r*r, r) r
   const double *tri;       // [n_tri][12] a e1 e2 n=e1×e2
   const int32_t *prim_mat; // [n_prims]   material index by class-major id
   const DevMaterial *mats;
@@ -47,11 +47,12 @@ struct DevScene {
   const unsigned char *blob;
   uint32_t blob_bytes;
   uint32_t off_ids, off_sph, off_mov, off_tri;
+  uint32_t off_pmat, off_mats;  // shading data inside the image: prim -> material, material records
   int32_t n_nodes;
   // scene image for the GRID kernel (rtow_grid.h): header, cells, ids, records
   const unsigned char *gblob;
   uint32_t gblob_bytes;
-  uint32_t g_off_cells, g_off_ids, g_off_sph, g_off_mov, g_off_tri;
+  uint32_t g_off_cells, g_off_ids, g_off_sph, g_off_mov, g_off_tri, g_off_pmat, g_off_mats;
 };
 
 struct FastDiv {  // unsigned division by a per-launch constant (see fastdiv() in the kernel)

@@ -27,6 +27,7 @@ namespace rtow {
 struct GridImage {
   std::vector<unsigned char> blob;
   uint32_t off_cells = 0, off_ids = 0, off_sph = 0, off_mov = 0, off_tri = 0;
+  uint32_t off_pmat = 0, off_mats = 0;  // material index per primitive, material records
   int32_t n[3] = {1, 1, 1};
   uint32_t n_large = 0;
   bool ok = false;  // false: scene not suited (e.g. lists too long) — use the BVH
@@ -42,7 +43,9 @@ struct B3 {
 inline void build_grid_image(const std::vector<double> &sph, const std::vector<double> &sph_r,
                              const std::vector<double> &mov, const std::vector<double> &tri,
                              const double cam_origin[3], GridImage &img, double cells_per_prim = 1.5,
-                             double large_ratio = 4.0, double time0 = 0.0, double time1 = 1.0) {
+                             double large_ratio = 4.0, double time0 = 0.0, double time1 = 1.0,
+                             const std::vector<int32_t> &prim_mat = {},
+                             const std::vector<unsigned char> &mats_bytes = {}) {
   using grid_detail::B3;
   const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
   const int np = ns + nm + nt;
@@ -158,8 +161,12 @@ inline void build_grid_image(const std::vector<double> &sph, const std::vector<d
   img.off_sph = (uint32_t)(img.off_ids + ids_bytes);
   img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
   img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
-  const size_t total = (size_t)img.off_tri + tri.size() * 8;
+  img.off_pmat = (uint32_t)((((size_t)img.off_tri + tri.size() * 8) + 15) / 16 * 16);
+  img.off_mats = (uint32_t)((((size_t)img.off_pmat + prim_mat.size() * 4) + 15) / 16 * 16);
+  const size_t total = (size_t)img.off_mats + mats_bytes.size();
   img.blob.assign(((total + 15) / 16) * 16, 0);
+  if (!prim_mat.empty()) std::memcpy(img.blob.data() + img.off_pmat, prim_mat.data(), prim_mat.size() * 4);
+  if (!mats_bytes.empty()) std::memcpy(img.blob.data() + img.off_mats, mats_bytes.data(), mats_bytes.size());
   img.n_large = (uint32_t)large.size();
 
   std::vector<int32_t> ids;

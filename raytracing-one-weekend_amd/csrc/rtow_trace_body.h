@@ -197,7 +197,7 @@ __device__ __forceinline__ void sphere_test(V3 o, V3 d, double a, double inv_a, 
                                             double cz, double r2, int id, double tmin, Closest &best) {
   V3 oc = {o.x - cx, o.y - cy, o.z - cz};
   double h = dot(oc, d);
-  double c = dot(oc, oc) - r2;
+  double c = dot(oc, oc) - fabs(r2);  // r2 carries the radius' sign (see rtow_capi.cpp)
   double disc = h * h - a * c;
   if (disc >= 0.0) {
     double sq = fast_sqrt(disc);
@@ -752,33 +752,74 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         if (depth <= 0) {
           need_sample = true;  // src/render.cpp:115: black
         } else {
-          // rebuild the Hit of the winner (src/common-model.cpp:83-90, :121)
+          // rebuild the Hit of the winner (src/common-model.cpp:83-90, :121).  The walking
+          // kernels read the winner's record, its material index and the material from the
+          // LDS scene image (a chain of three dependent loads: LDS latency, not L2's)
           V3 where = ro + rd * best.t;
           V3 normal;
           bool front = true;
           const int pid = best.prim;
-          if (pid < sc.n_sph + sc.n_mov) {
-            V3 center;
-            double radius;
-            if (pid < sc.n_sph) {
-              const double *q = sc.sph + 4 * (size_t)pid;
-              center = {q[0], q[1], q[2]};
-              radius = sc.sph_r[pid];
+          int mi, kind;
+          double m_fuzz, m_ir;
+          if constexpr (KERNEL >= 2) {
+            const uint32_t o_sph = KERNEL == 3 ? sc.g_off_sph : sc.off_sph;
+            const uint32_t o_mov = KERNEL == 3 ? sc.g_off_mov : sc.off_mov;
+            const uint32_t o_tri = KERNEL == 3 ? sc.g_off_tri : sc.off_tri;
+            const uint32_t o_pmat = KERNEL == 3 ? sc.g_off_pmat : sc.off_pmat;
+            const uint32_t o_mats = KERNEL == 3 ? sc.g_off_mats : sc.off_mats;
+            if (pid < sc.n_sph + sc.n_mov) {
+              V3 center;
+              double radius;
+              if (pid < sc.n_sph) {
+                const double2 p0 = im.d2(o_sph + 32u * (uint32_t)pid), p1 = im.d2(o_sph + 32u * (uint32_t)pid + 16u);
+                center = {p0.x, p0.y, p1.x};
+                radius = p1.y;  // signed r*r: only the sign is used below
+              } else {
+                const uint32_t r = o_mov + 64u * (uint32_t)(pid - sc.n_sph);
+                const double2 p0 = im.d2(r), p1 = im.d2(r + 16u), p2 = im.d2(r + 32u), p3 = im.d2(r + 48u);
+                center = {p0.x + rtime * p1.y, p0.y + rtime * p2.x, p1.x + rtime * p2.y};
+                radius = p3.x;  // signed r*r
+              }
+              normal = normalize(where - center);
+              front = (dot(rd, normal) < 0.0) ^ (radius < 0.0);
+              normal = front ? normal : -normal;
             } else {
-              const double *q = sc.mov + 8 * (size_t)(pid - sc.n_sph);
-              center = {q[0] + rtime * q[3], q[1] + rtime * q[4], q[2] + rtime * q[5]};
-              radius = q[7];
+              const uint32_t r = o_tri + 96u * (uint32_t)(pid - sc.n_sph - sc.n_mov);
+              const double2 q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
+              normal = {q4.y, q5.x, q5.y};
             }
-            normal = normalize(where - center);
-            front = (dot(rd, normal) < 0.0) ^ (radius < 0.0);
-            normal = front ? normal : -normal;
+            mi = (int)im.u32(o_pmat + 4u * (uint32_t)pid);
+            const uint32_t mr = o_mats + 48u * (uint32_t)mi;
+            const double2 m1 = im.d2(mr + 16u), m2 = im.d2(mr + 32u);  // {att.z, fuzz}, {ir, kind|pad}
+            m_fuzz = m1.y;
+            m_ir = m2.x;
+            kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
           } else {
-            const double *q = sc.tri + 12 * (size_t)(pid - sc.n_sph - sc.n_mov);
-            normal = {q[9], q[10], q[11]};
+            if (pid < sc.n_sph + sc.n_mov) {
+              V3 center;
+              double radius;
+              if (pid < sc.n_sph) {
+                const double *q = sc.sph + 4 * (size_t)pid;
+                center = {q[0], q[1], q[2]};
+                radius = sc.sph_r[pid];
+              } else {
+                const double *q = sc.mov + 8 * (size_t)(pid - sc.n_sph);
+                center = {q[0] + rtime * q[3], q[1] + rtime * q[4], q[2] + rtime * q[5]};
+                radius = q[7];
+              }
+              normal = normalize(where - center);
+              front = (dot(rd, normal) < 0.0) ^ (radius < 0.0);
+              normal = front ? normal : -normal;
+            } else {
+              const double *q = sc.tri + 12 * (size_t)(pid - sc.n_sph - sc.n_mov);
+              normal = {q[9], q[10], q[11]};
+            }
+            mi = sc.prim_mat[pid];
+            const DevMaterial *m = sc.mats + mi;
+            kind = m->kind;
+            m_fuzz = m->fuzz;
+            m_ir = m->ir;
           }
-          const int mi = sc.prim_mat[pid];
-          const DevMaterial *m = sc.mats + mi;
-          const int kind = m->kind;
 
           // ---- Material::scatter (src/common-model.cpp:13-62) ------------------
           // first unit-ball candidate of this bounce; its block also carries the coin
@@ -786,7 +827,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
           V3 rnd = rng_scatter(g, k0, k1, coin);
           V3 dirbase = {0.0, 0.0, 0.0};
           if (kind == 2) {
-            const double ir = m->ir;
+            const double ir = m_ir;
             const V3 unit = normalize(rd);
             const double cos_theta = dot(-unit, normal);
             const double sin_theta = fast_sqrt(1.0 - cos_theta * cos_theta);
@@ -816,7 +857,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
                        fabs(normal.z - rnd.z) < 1e-8;
             dir = normal + rnd;
           } else {
-            dir = dirbase + m->fuzz * rnd;
+            dir = dirbase + m_fuzz * rnd;
           }
           if (absorbed) {
             need_sample = true;  // src/render.cpp:120: black
@@ -834,9 +875,15 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         const double t = 0.5 * (unit.y + +1.0);
         V3 c = (1.0 - t) * V3{1.0, 1.0, 1.0} + t * V3{0.5, 0.7, 1.0};
         for (int q = nb - 1; q >= 0; --q) {
-          const uint32_t mi = P.stack[(size_t)q * P.n_lanes + lane_g];
-          const DevMaterial *m = sc.mats + mi;
-          c = V3{m->att[0], m->att[1], m->att[2]} * c;
+          const uint32_t smi = P.stack[(size_t)q * P.n_lanes + lane_g];
+          if constexpr (KERNEL >= 2) {
+            const uint32_t mr = (KERNEL == 3 ? sc.g_off_mats : sc.off_mats) + 48u * smi;
+            const double2 a0 = im.d2(mr), a1 = im.d2(mr + 16u);
+            c = V3{a0.x, a0.y, a1.x} * c;
+          } else {
+            const DevMaterial *m = sc.mats + smi;
+            c = V3{m->att[0], m->att[1], m->att[2]} * c;
+          }
         }
         acc = acc + c;  // pixel_color += ray_color(...)
         need_sample = true;
