@@ -93,11 +93,13 @@ def cpu_baseline(scene, height, seconds):
     import orc
 
     cores = host_cores()
-    cal = rtow.make_config(W, height, 1, 1, DEPTH, seed=SEED)
+    cal = rtow.make_config(W, height, 2, 1, DEPTH, seed=SEED)
+    orc.render(scene, rtow.make_config(64, 48, 1, 1, DEPTH, seed=SEED), orc.RNG_PHILOX, nthreads=cores)  # warm up
     t0 = time.perf_counter()
-    orc.render(scene, cal, orc.RNG_PHILOX, nthreads=cores)
+    _, cst = orc.render(scene, cal, orc.RNG_PHILOX, nthreads=cores)
     dt = max(time.perf_counter() - t0, 1e-3)
-    spp = int(max(1, min(64, seconds / dt)))
+    rate = cst.samples / dt  # samples per second of the oracle on this host
+    spp = int(max(1, min(256, seconds * rate / (W * height))))
     cfg = rtow.make_config(W, height, spp, 1, DEPTH, seed=SEED)
     t0 = time.perf_counter()
     _, st = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=cores)
