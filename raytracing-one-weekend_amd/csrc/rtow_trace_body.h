@@ -193,12 +193,26 @@ struct Closest {
 // the hit point and normal are computed once, for the winner only.
 // `inv_a` is 1/a, used only by the fast build (one reciprocal per ray instead of two
 // divisions per candidate hit); the strict build divides like the reference.
+__device__ __forceinline__ double sphere_disc(V3 o, V3 d, double a, double cx, double cy, double cz,
+                                              double r2, double &h) {
+  V3 oc = {o.x - cx, o.y - cy, o.z - cz};
+  h = dot(oc, d);
+  double c = dot(oc, oc) - fabs(r2);  // r2 carries the radius' sign (see rtow_capi.cpp)
+  return h * h - a * c;
+}
+
+__device__ __forceinline__ void sphere_resolve(double disc, double h, double a, double inv_a, int id,
+                                               double tmin, Closest &best);
+
 __device__ __forceinline__ void sphere_test(V3 o, V3 d, double a, double inv_a, double cx, double cy,
                                             double cz, double r2, int id, double tmin, Closest &best) {
-  V3 oc = {o.x - cx, o.y - cy, o.z - cz};
-  double h = dot(oc, d);
-  double c = dot(oc, oc) - fabs(r2);  // r2 carries the radius' sign (see rtow_capi.cpp)
-  double disc = h * h - a * c;
+  double h;
+  const double disc = sphere_disc(o, d, a, cx, cy, cz, r2, h);
+  sphere_resolve(disc, h, a, inv_a, id, tmin, best);
+}
+
+__device__ __forceinline__ void sphere_resolve(double disc, double h, double a, double inv_a, int id,
+                                               double tmin, Closest &best) {
   if (disc >= 0.0) {
     double sq = fast_sqrt(disc);
 #ifdef RTOW_FAST_MATH
@@ -481,9 +495,50 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   const int nx = hi[9], ny = hi[10], nz = hi[11];
   const uint32_t n_large = (uint32_t)hi[12], off_large = (uint32_t)hi[13];
 
-  // the large primitives, for every ray
-  if (active && n_large != 0u)
-    leaf_test(im, sc, off, (off_large - off.ids) >> 2, n_large, o, d, a, inv_a, time, best, nprim, last_id);
+  // the large primitives, for every ray.  Static spheres are taken four (then two) at a time:
+  // all records are loaded and all discriminants computed before any hit branch, so LDS
+  // latency and the f64 dependency chains of one test overlap the others.
+  if (active && n_large != 0u) {
+    const uint32_t lf = (off_large - off.ids) >> 2;
+    uint32_t k = 0;
+    for (; k + 3 < n_large; k += 4) {
+      int id[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) id[j] = (int)im.u32(off.ids + 4u * (lf + k + j));
+      if (id[0] < sc.n_sph && id[1] < sc.n_sph && id[2] < sc.n_sph && id[3] < sc.n_sph) {
+        double dd[4], hh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t r = off.sph + 32u * (uint32_t)id[j];
+          const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
+          dd[j] = sphere_disc(o, d, a, p0.x, p0.y, p1.x, p1.y, hh[j]);
+        }
+        nprim += 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sphere_resolve(dd[j], hh[j], a, inv_a, id[j], RTOW_TMIN, best);
+        last_id = id[3];
+      } else {
+        leaf_test(im, sc, off, lf + k, 4u, o, d, a, inv_a, time, best, nprim, last_id);
+      }
+    }
+    for (; k + 1 < n_large; k += 2) {
+      const int ia = (int)im.u32(off.ids + 4u * (lf + k)), ib = (int)im.u32(off.ids + 4u * (lf + k + 1));
+      if (ia < sc.n_sph && ib < sc.n_sph) {
+        const uint32_t ra = off.sph + 32u * (uint32_t)ia, rb = off.sph + 32u * (uint32_t)ib;
+        const double2 a0 = im.d2(ra), a1 = im.d2(ra + 16u), b0 = im.d2(rb), b1 = im.d2(rb + 16u);
+        double ha, hb;
+        const double da = sphere_disc(o, d, a, a0.x, a0.y, a1.x, a1.y, ha);
+        const double db = sphere_disc(o, d, a, b0.x, b0.y, b1.x, b1.y, hb);
+        nprim += 2u;
+        sphere_resolve(da, ha, a, inv_a, ia, RTOW_TMIN, best);
+        sphere_resolve(db, hb, a, inv_a, ib, RTOW_TMIN, best);
+        last_id = ib;
+      } else {
+        leaf_test(im, sc, off, lf + k, 2u, o, d, a, inv_a, time, best, nprim, last_id);
+      }
+    }
+    if (k < n_large) leaf_test(im, sc, off, lf + k, n_large - k, o, d, a, inv_a, time, best, nprim, last_id);
+  }
   float tmax32 = __double2float_ru(best.t);
 
   // clip the ray to the grid bounds (f32, conservative by the padding of rtow_grid.h)
