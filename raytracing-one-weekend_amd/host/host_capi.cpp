@@ -6,7 +6,7 @@
 #include <string>
 
 #include "../../include/rtow.h"
-#include "random-utils.h"
+#include "scene_rng.h"
 #include "render.h"
 
 namespace rtweekend::detail {

@@ -10,7 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "random-utils.h"
+#include "scene_rng.h"
 #include "render.h"
 
 namespace rt = rtweekend;
