@@ -276,6 +276,24 @@ def test_device_tonemap_equals_reference_write_color(ctx):
     assert tuple(want[0, 0]) == (0, 255, 255)
 
 
+@pytest.mark.parametrize("name,w,spp", [("cover_static", 960, 8), ("cover_moving", 960, 8), ("suzanne", 800, 6)])
+def test_large_strict_parity_all_kernels(ctx, name, w, spp):
+    """Millions of samples per scene, strict build, every closest-hit strategy against the oracle,
+    bit for bit: the f32 culling of the BVH boxes and of the grid cells must never drop a hit the
+    exact test accepts (≈5 M samples / 12 M segments per case; the oracle walks the reference's BVH)."""
+    kind, args, _, aspect, _, _, depth, seed = CASES[name]
+    scene = make_scene(kind, args)
+    h = rtow.image_height(w, aspect)
+    cfg0 = rtow.make_config(w, h, spp, 2, depth, seed=seed + 1000, precision=rtow.F64_STRICT)
+    ref, ost = orc.render(scene, cfg0, orc.RNG_PHILOX, nthreads=16)
+    kernels = [rtow.KERNEL_BVH, rtow.KERNEL_GRID] + ([rtow.KERNEL_BRUTE] if name != "suzanne" else [])
+    for k in kernels:
+        cfg = rtow.make_config(w, h, spp, 2, depth, seed=seed + 1000, precision=rtow.F64_STRICT, kernel=k)
+        img, st = ctx.render(scene, cfg)
+        assert st.segments == ost.segments, (k, st.segments, ost.segments)
+        assert np.array_equal(img, ref), (k, int((img != ref).sum()))
+
+
 def test_image_does_not_depend_on_the_partition(ctx):
     scene = rtow.HostScene.cover(11, 1.5, True)
     W, H = 50, 37
