@@ -294,6 +294,50 @@ def test_large_strict_parity_all_kernels(ctx, name, w, spp):
         assert np.array_equal(img, ref), (k, int((img != ref).sum()))
 
 
+def test_grid_global_image_path_many_spheres(ctx):
+    """30,000 small spheres + a ground sphere: the grid scene image (~1.3 MB) does not fit LDS, so
+    the GRID kernel walks it in global memory.  Strict build vs oracle, bit for bit; BVH likewise."""
+    import ctypes as C
+
+    n = 30000
+    rng = np.random.default_rng(11)
+    geom = np.zeros((n + 1, 4))
+    geom[0] = [0, -1000, 0, 1000]
+    geom[1:, 0] = rng.uniform(-30, 30, n)
+    geom[1:, 2] = rng.uniform(-30, 30, n)
+    geom[1:, 3] = rng.uniform(0.03, 0.12, n)
+    geom[1:, 1] = geom[1:, 3] + rng.uniform(0, 1.5, n)
+    mats = (rtow.Material * 3)()
+    for i, (kind, alb) in enumerate([(rtow.MAT_LAMBERTIAN, (0.5, 0.5, 0.5)), (rtow.MAT_METAL, (0.8, 0.7, 0.6)),
+                                     (rtow.MAT_DIELECTRIC, (0, 0, 0))]):
+        mats[i].kind = kind
+        mats[i].albedo = (C.c_double * 3)(*alb)
+        mats[i].fuzz = 0.1 if kind == rtow.MAT_METAL else 0.0
+        mats[i].ir = 1.5
+    base = rtow.HostScene.cover(0, 1.5, False)
+    sc = rtow.Scene()
+    sc.camera = base.c.camera
+    g = np.ascontiguousarray(geom)
+    mi = np.concatenate([[0], rng.integers(0, 3, n)]).astype(np.int32)
+    kinds = np.zeros(n + 1, dtype=np.int32)
+    idx = np.arange(n + 1, dtype=np.int32)
+    sc.n_spheres = n + 1
+    sc.sphere_geom = g.ctypes.data_as(C.POINTER(C.c_double))
+    sc.sphere_mat = mi.ctypes.data_as(C.POINTER(C.c_int32))
+    sc.n_materials = 3
+    sc.materials = mats
+    sc.n_prims = n + 1
+    sc.prim_kind = kinds.ctypes.data_as(C.POINTER(C.c_int32))
+    sc.prim_index = idx.ctypes.data_as(C.POINTER(C.c_int32))
+    cfg0 = rtow.make_config(240, 160, 4, 2, 30, seed=21, precision=rtow.F64_STRICT)
+    ref, ost = orc.render(sc, cfg0, orc.RNG_PHILOX, nthreads=16)
+    for k in (rtow.KERNEL_GRID, rtow.KERNEL_BVH):
+        cfg = rtow.make_config(240, 160, 4, 2, 30, seed=21, precision=rtow.F64_STRICT, kernel=k)
+        img, st = ctx.render(sc, cfg)
+        assert st.kernel_used == k
+        assert st.segments == ost.segments and np.array_equal(img, ref), (k, int((img != ref).sum()))
+
+
 def test_image_does_not_depend_on_the_partition(ctx):
     scene = rtow.HostScene.cover(11, 1.5, True)
     W, H = 50, 37
