@@ -94,3 +94,25 @@ def test_cli_dry_run_prints_the_reference_config_text():
                    "image_width: 400\nsamples_per_pixel: 10\nmax_child_rays: 20\nnthreads: 2\n}\n")
     r = subprocess.run([str(exe), "--bogus"], capture_output=True, text=True)
     assert r.returncode != 0 and "not expected" in r.stderr
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ has every field the driver's contract names, is
+    consistent with BASELINE.json, and carries the roofline and cpu_baseline objects."""
+    import json
+
+    base = json.loads((REPO / "BASELINE.json").read_text())
+    line = json.loads((REPO / "profiles" / "r01_f_bench_final.json").read_text())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["metric"] == base["metric"] and line["unit"] == "Msamples/s"
+    assert line["dtype"] == "f64" and line["vs_baseline"] is None and line["higher_is_better"] is True
+    assert "workload" in line["config"] and "1200x800, 100 spp, 50 bounces" in line["config"]["workload"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    samples = 1200 * 800 * line["config"]["spp_effective"]
+    assert abs(line["value"] - samples / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "Msamples/s"
