@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid"], default="auto")
     ap.add_argument("--moving", action="store_true", help="moving-sphere variant of the cover scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", choices=["tiles", "samples"], default="tiles",
+                    help="N>1 decomposition: strips of rows + one gather (default, bit-identical for any N) "
+                         "or the reference's own: full frame per rank with spp/N of the samples, frames summed")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 path with every rank on cuda:0 (1-GPU box)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -139,8 +142,14 @@ def main():
     tile_rows = 4 if H % (4 * world) == 0 else 8
     precision = rtow.F64_FAST if a.precision == "fast" else rtow.F64_STRICT
     kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID}[a.kernel]
-    cfg = rtow.make_config(W, H, spp, nstreams, DEPTH, seed=SEED, precision=precision,
-                           kernel=kernel, rank=rank, nranks=world, tile_rows=tile_rows)
+    split_samples = a.split == "samples" and world > 1
+    if split_samples:
+        s_first, s_count = tiles.stream_range(nstreams, world, rank)
+        cfg = rtow.make_config(W, H, spp, nstreams, DEPTH, seed=SEED, precision=precision, kernel=kernel,
+                               stream_first=s_first, stream_count=s_count)
+    else:
+        cfg = rtow.make_config(W, H, spp, nstreams, DEPTH, seed=SEED, precision=precision,
+                               kernel=kernel, rank=rank, nranks=world, tile_rows=tile_rows)
 
     scene = rtow.HostScene.cover(11, ASPECT, a.moving)  # default mt19937 seed: 486 / 485 prims
     n_prims = scene.c.n_prims
@@ -148,8 +157,12 @@ def main():
     ctx.upload(scene)  # scene resident in HBM before the timed region
 
     rows = rtow.local_rows(cfg)
-    sg = tiles.StripGather(H, W, tile_rows, rank, world, torch.device("cpu") if rehearsal else dev)
-    assert sg.rows == rows
+    if split_samples:
+        sg = tiles.FrameSum(H, W, rank, world, torch.device("cpu") if rehearsal else dev)
+        sg.gather = sg.reduce
+    else:
+        sg = tiles.StripGather(H, W, tile_rows, rank, world, torch.device("cpu") if rehearsal else dev)
+        assert sg.rows == rows
     local = torch.zeros_like(sg.local, device=dev) if rehearsal else sg.local
     stream = torch.cuda.current_stream(dev)
 
@@ -242,7 +255,9 @@ def main():
             "config": {
                 "workload": f"RTOW cover scene ({n_prims} prims, {'moving' if a.moving else 'static'}) "
                             f"{W}x{H}, {spp} spp, {DEPTH} bounces"
-                            + ("" if world == 1 else f", {tile_rows}-row strips over {world} GPUs + 1 RCCL gather"),
+                            + ("" if world == 1 else
+                               (f", sample-split over {world} GPUs + gather of full frames" if split_samples else
+                                f", {tile_rows}-row strips over {world} GPUs + 1 RCCL gather")),
                 "baseline_config": "configs[1]" if (world == 1 and spp == 100) else
                                    ("configs[2]" if spp == 500 else "custom"),
                 "spp_effective": spp_eff, "samples_per_item": spp // nstreams, "nstreams": nstreams,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTOW_ABI_VERSION 1
+#define RTOW_ABI_VERSION 2
 
 /* error codes */
 #define RTOW_OK 0
@@ -135,6 +135,16 @@ typedef struct rtow_config_t {
   int32_t nranks;     /* tile_rows rows dealt round-robin; strip t belongs to    */
   int32_t tile_rows;  /* rank t % nranks.  nranks=1 → whole image.               */
   uint64_t seed;
+  /* Stream range (progressive accumulation, sample-split decompositions).
+   * stream_count == 0: all nstreams streams.  Otherwise only streams [stream_first,
+   * stream_first + stream_count) are traced; sample indices and random numbers are those of the
+   * full render.  accumulate != 0: the new partial images are added onto the sums already in the
+   * output buffer, in stream order — rendering [0,a) and then [a,n) with accumulate set gives
+   * bit for bit the sums of one call over [0,n). */
+  int32_t stream_first;
+  int32_t stream_count;
+  int32_t accumulate;
+  int32_t pad_;
 } rtow_config_t;
 
 typedef struct rtow_stats_t {

@@ -1008,7 +1008,11 @@ int orc_render(const rtow_scene_t *scene, const rtow_config_t *cfg, int rng_mode
   const std::vector<int> rows = local_rows(*cfg);
   const int spt = cfg->samples_per_pixel / cfg->nstreams;  // src/render.cpp:174
   const size_t npx = rows.size() * (size_t)W;
-  std::fill(rgb_sums, rgb_sums + npx * 3, 0.0);
+  // stream range / accumulation (include/rtow.h): streams [k_first, k_end), continuing from the
+  // caller's sums when cfg->accumulate is set
+  const int k_first = cfg->stream_count > 0 ? cfg->stream_first : 0;
+  const int k_end = cfg->stream_count > 0 ? cfg->stream_first + cfg->stream_count : cfg->nstreams;
+  if (!cfg->accumulate) std::fill(rgb_sums, rgb_sums + npx * 3, 0.0);
   Counters total;
   uint64_t rng_doubles = 0;
 
@@ -1017,7 +1021,7 @@ int orc_render(const rtow_scene_t *scene, const rtow_config_t *cfg, int rng_mode
     // nstreams == 1 this is exactly the reference at `-t 1`.
     MtGlobal rng;
     std::vector<double> local(npx * 3);
-    for (int k = 0; k < cfg->nstreams; ++k) {
+    for (int k = k_first; k < k_end; ++k) {
       for (size_t li = 0; li < rows.size(); ++li) {
         int i = rows[li];
         for (int j = 0; j < W; ++j) {
@@ -1044,8 +1048,8 @@ int orc_render(const rtow_scene_t *scene, const rtow_config_t *cfg, int rng_mode
         int i = rows[li];
         for (int j = 0; j < W; ++j) {
           uint32_t pixel_id = (uint32_t)(i * W + j);
-          V3 global{0, 0, 0};
-          for (int k = 0; k < cfg->nstreams; ++k) {
+          V3 global = load3(&rgb_sums[(li * W + j) * 3]);
+          for (int k = k_first; k < k_end; ++k) {
             V3 partial{0, 0, 0};
             for (int s = 0; s < spt; ++s) {
               rng.begin_sample(pixel_id, (uint32_t)(k * spt + s));
@@ -1076,7 +1080,7 @@ int orc_render(const rtow_scene_t *scene, const rtow_config_t *cfg, int rng_mode
     }
   }
   if (stats) {
-    stats->samples = (uint64_t)npx * (uint64_t)spt * (uint64_t)cfg->nstreams;
+    stats->samples = (uint64_t)npx * (uint64_t)spt * (uint64_t)(k_end - k_first);
     stats->segments = total.segments;
     stats->prim_tests = total.prim_tests;
     stats->node_tests = total.node_tests;

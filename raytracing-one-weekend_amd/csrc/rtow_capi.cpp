@@ -374,6 +374,11 @@ static int validate_cfg(const rtow_config_t *cfg) {
     return fail(RTOW_EINVAL, "unknown kernel %d", cfg->kernel);
   if ((long long)cfg->image_width * cfg->image_height > 0x7fffffffLL)
     return fail(RTOW_EINVAL, "image too large");
+  if (cfg->stream_first < 0 || cfg->stream_count < 0 ||
+      (cfg->stream_count > 0 && cfg->stream_first + cfg->stream_count > cfg->nstreams) ||
+      (cfg->stream_count == 0 && cfg->stream_first != 0))
+    return fail(RTOW_EINVAL, "stream range [%d, %d+%d) outside [0, %d)", cfg->stream_first, cfg->stream_first,
+                cfg->stream_count, cfg->nstreams);
   return RTOW_OK;
 }
 
@@ -412,7 +417,8 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   const int rows = rtow_local_rows(cfg);
   const int spt = cfg->samples_per_pixel / cfg->nstreams;  // src/render.cpp:174
   const unsigned long long npix = (unsigned long long)rows * cfg->image_width;
-  const unsigned long long n_items = npix * (unsigned long long)cfg->nstreams;
+  const int streams_now = cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams;
+  const unsigned long long n_items = npix * (unsigned long long)streams_now;
   if (n_items > 0xfffffff0ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
 
   int kernel = cfg->kernel;
@@ -443,7 +449,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   if (npix == 0) return RTOW_OK;
   if (spt == 0) {
     // fewer samples than streams: zero effective samples (src/render.cpp:174), black sums
-    HIPCHK(hipMemsetAsync(d_rgb_sums, 0, (size_t)npix * 3 * sizeof(double), st));
+    if (!cfg->accumulate) HIPCHK(hipMemsetAsync(d_rgb_sums, 0, (size_t)npix * 3 * sizeof(double), st));
     if (stats) HIPCHK(hipStreamSynchronize(st));
     return RTOW_OK;
   }
@@ -479,7 +485,8 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.W = cfg->image_width;
   P.H = cfg->image_height;
   P.spt = spt;
-  P.nstreams = cfg->nstreams;
+  P.nstreams = streams_now;
+  P.stream_first = cfg->stream_first;
   P.max_child_rays = cfg->max_child_rays;
   P.rank = cfg->rank;
   P.nranks = cfg->nranks;
@@ -532,7 +539,8 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   R.partials = P.partials;
   R.out = (double *)d_rgb_sums;
   R.npix3 = (uint32_t)(npix * 3);
-  R.nstreams = cfg->nstreams;
+  R.nstreams = streams_now;
+  R.accumulate = cfg->accumulate;
   R.W = (uint32_t)cfg->image_width;
   R.tile_w_log2 = tw;
   R.tile_h_log2 = th;
@@ -552,7 +560,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
       HIPCHK(hipEventElapsedTime(&ms, c->ev[slot][0], c->ev[slot][1]));
       stats->kernel_ms = ms;
     }
-    stats->samples = npix * (unsigned long long)spt * (unsigned long long)cfg->nstreams;
+    stats->samples = npix * (unsigned long long)spt * (unsigned long long)streams_now;
     stats->segments = c->h_counters[1];
     if (kernel == RTOW_KERNEL_BRUTE) {
       stats->prim_tests = stats->segments * (unsigned long long)c->n_prims;
@@ -624,6 +632,13 @@ int rtow_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg
   }
   void *d_out = nullptr;
   HIPCHK(hipMalloc(&d_out, bytes));
+  if (cfg->accumulate) {  // continue from the caller's sums
+    hipError_t e0 = hipMemcpy(d_out, rgb_sums_host, bytes, hipMemcpyHostToDevice);
+    if (e0 != hipSuccess) {
+      (void)hipFree(d_out);
+      return fail(RTOW_EHIP, "H2D copy failed: %s", hipGetErrorString(e0));
+    }
+  }
   rc = rtow_render_device(c, cfg, d_out, nullptr, stats ? stats : &local);
   if (rc == RTOW_OK) {
     hipError_t e = hipMemcpy(rgb_sums_host, d_out, bytes, hipMemcpyDeviceToHost);

@@ -65,7 +65,8 @@ struct TraceParams {
                            // (by value it pinned 42 SGPRs across the whole kernel)
   int32_t W, H;            // full image
   int32_t spt;             // samples per stream (= spp / nstreams)
-  int32_t nstreams;
+  int32_t nstreams;        // streams traced by THIS launch
+  int32_t stream_first;    // global index of its first stream (sample index = stream * spt + s)
   int32_t max_child_rays;
   int32_t rank, nranks, tile_rows;
   int32_t local_rows;
@@ -89,6 +90,7 @@ struct ReduceParams {
   double *out;             // [local_rows*W][3], row-major
   uint32_t npix3;          // local_rows*W*3
   int32_t nstreams;
+  int32_t accumulate;      // start from the sums already in `out`
   uint32_t W, tile_w_log2, tile_h_log2, tiles_per_row;
 };
 

@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(256) rtow_reduce_streams(const ReduceParams p)
     const uint32_t w = ((lr & ((1u << p.tile_h_log2) - 1u)) << p.tile_w_log2) | (j & ((1u << p.tile_w_log2) - 1u));
     src = (((tr * p.tiles_per_row + tc) << 6) | w) * 3u + c;
   }
-  double g = 0.0;
+  double g = p.accumulate ? p.out[idx] : 0.0;
   for (int k = 0; k < p.nstreams; ++k) g = p.partials[(size_t)k * p.npix3 + src] + g;
   p.out[idx] = g;
 }

@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
           const uint32_t rr = lr - q * (uint32_t)P.tile_rows;
           gi = (q * (uint32_t)P.nranks + (uint32_t)P.rank) * (uint32_t)P.tile_rows + rr;
           g.pixel = gi * (uint32_t)P.W + j;
-          g.sample = k * (uint32_t)P.spt;  // first sample index of this stream
+          g.sample = (k + (uint32_t)P.stream_first) * (uint32_t)P.spt;  // first sample index of this stream
           s_left = P.spt;
           acc = {0.0, 0.0, 0.0};
         }

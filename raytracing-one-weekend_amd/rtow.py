@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 LIB_PATH = Path(os.environ.get("RTOW_LIB", PKG_DIR / "librtow.so"))  # RTOW_LIB: A/B against another build
 
-RTOW_ABI_VERSION = 1
+RTOW_ABI_VERSION = 2
 RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY = 0, -1, -2, -3, -4, -5
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
@@ -62,6 +62,8 @@ class Config(C.Structure):
         ("max_child_rays", C.c_int32), ("precision", C.c_int32), ("kernel", C.c_int32),
         ("rank", C.c_int32), ("nranks", C.c_int32), ("tile_rows", C.c_int32),
         ("seed", C.c_uint64),
+        ("stream_first", C.c_int32), ("stream_count", C.c_int32), ("accumulate", C.c_int32),
+        ("pad_", C.c_int32),
     ]
 
 
@@ -148,9 +150,10 @@ def image_height(width: int, aspect_ratio: float) -> int:
 
 
 def make_config(width, height, spp, nstreams=1, max_child_rays=50, seed=1, precision=F64_FAST,
-                kernel=KERNEL_AUTO, rank=0, nranks=1, tile_rows=8) -> Config:
+                kernel=KERNEL_AUTO, rank=0, nranks=1, tile_rows=8, stream_first=0, stream_count=0,
+                accumulate=0) -> Config:
     return Config(width, height, spp, nstreams, max_child_rays, precision, kernel, rank, nranks,
-                  tile_rows, seed)
+                  tile_rows, seed, stream_first, stream_count, accumulate, 0)
 
 
 def spp_effective(cfg: Config) -> int:
@@ -254,15 +257,16 @@ class Context:
         check(lib().rtow_tonemap_device(self._h, C.c_void_p(d_sums), n_values, spp_eff,
                                         C.c_void_p(d_rgb8), C.c_void_p(stream)), "rtow_tonemap_device")
 
-    def render(self, scene, cfg: Config):
-        """Upload + render + D2H: returns (numpy [rows, W, 3] float64 sums, Stats)."""
+    def render(self, scene, cfg: Config, into=None):
+        """Upload + render + D2H: returns (numpy [rows, W, 3] float64 sums, Stats).  `into`: an
+        existing sums array to accumulate onto (cfg.accumulate)."""
         import numpy as np
 
         s = scene.c if isinstance(scene, HostScene) else scene
         rows = lib().rtow_local_rows(C.byref(cfg))
         if rows < 0:
             check(rows, "rtow_local_rows")
-        out = np.zeros((rows, cfg.image_width, 3), dtype=np.float64)
+        out = np.zeros((rows, cfg.image_width, 3), dtype=np.float64) if into is None else into
         st = Stats()
         check(lib().rtow_render(self._h, C.byref(s), C.byref(cfg), out.ctypes.data_as(_pd),
                                 C.byref(st)), "rtow_render")

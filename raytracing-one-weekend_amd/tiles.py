@@ -54,3 +54,40 @@ class StripGather:
             if n:
                 self.image.index_copy_(0, self.index[r], self.parts[r][:n])
         return self.image
+
+
+# ---- sample-split decomposition ------------------------------------
+# The reference's own parallelism: every worker renders the WHOLE frame with spp/N of the
+# samples and the partial frames are added in worker order (src/render.cpp:169-180).  Here a
+# worker is a rank and its samples are a contiguous range of streams.  Unlike the strip
+# partition, the result depends on N in the last bits (the sum is re-associated), exactly as
+# the reference's result depends on its thread count; and the message is N full frames.
+
+
+def stream_range(nstreams: int, world: int, rank: int):
+    """(first, count) of the streams rank `rank` renders: contiguous, sizes differ by at most 1."""
+    base, extra = divmod(nstreams, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+class FrameSum:
+    """Gather full frames from all ranks and add them in rank order on rank dst."""
+
+    def __init__(self, height, width, rank, world, device, dst=0):
+        self.rank, self.world, self.dst = rank, world, dst
+        self.local = torch.zeros((height, width, 3), dtype=torch.float64, device=device)
+        self.parts = [torch.empty_like(self.local) for _ in range(world)] if rank == dst else None
+        self.image = torch.zeros_like(self.local) if rank == dst else None
+
+    def reduce(self):
+        if self.world == 1:
+            self.image.copy_(self.local)
+            return self.image
+        dist.gather(self.local, self.parts if self.rank == self.dst else None, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        self.image.zero_()
+        for r in range(self.world):  # global = done + global, workers in launch order (render.cpp:176-180)
+            torch.add(self.parts[r], self.image, out=self.image)
+        return self.image

@@ -118,13 +118,13 @@ class OrcScene:
             pass
 
 
-def render(scene, cfg: rtow.Config, rng_mode=RNG_PHILOX, nthreads=1):
-    """Returns (sums [rows, W, 3] float64, OrcStats)."""
+def render(scene, cfg: rtow.Config, rng_mode=RNG_PHILOX, nthreads=1, into=None):
+    """Returns (sums [rows, W, 3] float64, OrcStats).  `into`: sums to accumulate onto."""
     s = scene.c if hasattr(scene, "c") else scene
     tile = max(cfg.tile_rows, 1)
     nr = max(cfg.nranks, 1)
     rows = sum(1 for i in range(cfg.image_height) if (i // tile) % nr == cfg.rank)
-    out = np.zeros((rows, cfg.image_width, 3), dtype=np.float64)
+    out = np.zeros((rows, cfg.image_width, 3), dtype=np.float64) if into is None else into
     st = OrcStats()
     rc = lib().orc_render(C.byref(s), C.byref(cfg), rng_mode, nthreads, out.ctypes.data_as(_pd),
                           C.byref(st))

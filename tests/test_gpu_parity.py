@@ -338,6 +338,27 @@ def test_grid_global_image_path_many_spheres(ctx):
         assert st.segments == ost.segments and np.array_equal(img, ref), (k, int((img != ref).sum()))
 
 
+def test_progressive_accumulation_is_bit_identical(ctx):
+    """SURVEY §8 row f3 mechanism: stream ranges + accumulate.  Three calls [0,2) [2,3) [3,6) that
+    accumulate give the sums of one call (and of the oracle) bit for bit, on both walking kernels."""
+    scene = rtow.HostScene.cover(11, 1.5, True)
+    for kernel in (rtow.KERNEL_GRID, rtow.KERNEL_BVH):
+        one = rtow.make_config(70, 46, 18, 6, 25, seed=12, precision=rtow.F64_STRICT, kernel=kernel)
+        full, fst = ctx.render(scene, one)
+        acc, tot = None, 0
+        for first, count in ((0, 2), (2, 1), (3, 3)):
+            cfg = rtow.make_config(70, 46, 18, 6, 25, seed=12, precision=rtow.F64_STRICT, kernel=kernel,
+                                   stream_first=first, stream_count=count, accumulate=int(acc is not None))
+            acc, st = ctx.render(scene, cfg, into=acc)
+            tot += st.segments
+        assert np.array_equal(acc, full) and tot == fst.segments
+    ref, _ = orc.render(scene, rtow.make_config(70, 46, 18, 6, 25, seed=12), orc.RNG_PHILOX, nthreads=4)
+    assert np.array_equal(full, ref)
+    L = rtow.lib()
+    bad = rtow.make_config(8, 8, 4, 2, 5, stream_first=1, stream_count=2)
+    assert L.rtow_local_rows(C.byref(bad)) == rtow.RTOW_EINVAL and b"stream range" in L.rtow_last_error()
+
+
 def test_image_does_not_depend_on_the_partition(ctx):
     scene = rtow.HostScene.cover(11, 1.5, True)
     W, H = 50, 37

@@ -69,3 +69,49 @@ def test_strip_rows_match_the_c_abi():
             seen += tiles.strip_rows(H, tile, n, r)
         assert sorted(seen) == list(range(H))
         assert tiles.max_rows(H, tile, n) == max(len(tiles.strip_rows(H, tile, n, r)) for r in range(n))
+
+
+def _split_worker(rank, world, port, H, W, spp, nstreams, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import orc
+
+        scene = orc.OrcScene.cover(3, W / H, True)
+        first, count = tiles.stream_range(nstreams, world, rank)
+        cfg = rtow.make_config(W, H, spp, nstreams, 10, seed=5, stream_first=first, stream_count=count)
+        part, _ = orc.render(scene, cfg, orc.RNG_PHILOX)
+        fs = tiles.FrameSum(H, W, rank, world, torch.device("cpu"))
+        fs.local.copy_(torch.from_numpy(part))
+        img = fs.reduce()
+        if rank == 0:
+            np.save(out_path, img.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sample_split_frames_sum_in_rank_order(tmp_path, world):
+    """Row f3: every rank renders the whole frame for its stream range; rank 0 adds the frames in
+    rank order.  Equals the same sum formed in one process (and the single-rank image to rounding)."""
+    import orc
+
+    H, W, spp, ns = 20, 30, 12, 6
+    out = tmp_path / "img.npy"
+    mp.spawn(_split_worker, args=(world, _free_port(), H, W, spp, ns, str(out)), nprocs=world, join=True)
+    got = np.load(out)
+    scene = orc.OrcScene.cover(3, W / H, True)
+    want = np.zeros((H, W, 3))
+    seen = []
+    for r in range(world):
+        first, count = tiles.stream_range(ns, world, r)
+        seen += list(range(first, first + count))
+        part, _ = orc.render(scene, rtow.make_config(W, H, spp, ns, 10, seed=5, stream_first=first,
+                                                     stream_count=count), orc.RNG_PHILOX)
+        want = part + want
+    assert seen == list(range(ns))
+    assert np.array_equal(got, want)
+    whole, _ = orc.render(scene, rtow.make_config(W, H, spp, ns, 10, seed=5), orc.RNG_PHILOX)
+    assert np.allclose(got, whole, rtol=1e-13, atol=1e-13)

@@ -186,3 +186,21 @@ def test_t3_philox_vs_mt19937_rmse_against_two_independent_mt_runs():
     assert rmse_phi <= 1.5 * rmse_ref, (rmse_phi, rmse_ref)
     # means: the Monte-Carlo noise of an image mean at this size is ~0.3/255; allow 1/255
     assert np.all(np.abs(to8(a).mean(axis=(0, 1)) - to8(c).mean(axis=(0, 1))) < 1.0)
+
+
+def test_stream_ranges_and_accumulation_are_bit_identical_to_one_call():
+    """include/rtow.h stream_first / stream_count / accumulate: [0,a) then [a,n) accumulated ==
+    one call over [0,n), bit for bit (same samples, same summation order)."""
+    scene = orc.OrcScene.cover(5, 1.5, True)
+    full_cfg = rtow.make_config(40, 26, 12, 4, 12, seed=17)
+    full, fst = orc.render(scene, full_cfg, orc.RNG_PHILOX, nthreads=2)
+    a_cfg = rtow.make_config(40, 26, 12, 4, 12, seed=17, stream_first=0, stream_count=1)
+    b_cfg = rtow.make_config(40, 26, 12, 4, 12, seed=17, stream_first=1, stream_count=3, accumulate=1)
+    acc, sa = orc.render(scene, a_cfg, orc.RNG_PHILOX)
+    acc, sb = orc.render(scene, b_cfg, orc.RNG_PHILOX, nthreads=2, into=acc)
+    assert np.array_equal(acc, full)
+    assert sa.samples + sb.samples == fst.samples and sa.segments + sb.segments == fst.segments
+    # a range alone is a different (smaller) estimate
+    part, _ = orc.render(scene, rtow.make_config(40, 26, 12, 4, 12, seed=17, stream_first=2, stream_count=2),
+                         orc.RNG_PHILOX)
+    assert not np.array_equal(part, full) and part.sum() < full.sum()
