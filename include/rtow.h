@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTOW_ABI_VERSION 2
+#define RTOW_ABI_VERSION 3
 
 /* error codes */
 #define RTOW_OK 0
@@ -170,6 +170,31 @@ void rtow_ctx_destroy(rtow_ctx *ctx);
 /* Copy the scene into HBM (and build the device BVH).  The scene stays
  * resident until the next upload or ctx destroy. */
 int rtow_scene_upload(rtow_ctx *ctx, const rtow_scene_t *scene);
+
+/* Who builds the BVH image at rtow_scene_upload (replaces the reference's BVHNode constructor,
+ * src/render.cpp:73-110, which runs on the host inside render()):
+ *   HOST_SAH    binned surface-area-heuristic build on the host (default; best tree)
+ *   DEVICE_LBVH Morton codes + radix sort + Karras' radix tree + refit, all on the GPU
+ *               (csrc/rtow_build.hip) — for scenes rebuilt every frame
+ * Images are bit-identical with either builder (the closest hit is tree-independent).
+ * Takes effect at the next upload; the environment variable RTOW_BUILDER=host|device sets the
+ * default of new contexts. */
+#define RTOW_BUILDER_HOST_SAH 0
+#define RTOW_BUILDER_DEVICE_LBVH 1
+int rtow_ctx_set_builder(rtow_ctx *ctx, int32_t builder);
+
+typedef struct rtow_build_info_t {
+  int32_t builder;          /* builder that produced the resident BVH image */
+  int32_t bvh_nodes;        /* node records (without the END record) */
+  int32_t bvh_image_bytes;
+  int32_t grid_image_bytes; /* 0 = scene not suited to the grid */
+  double bvh_build_ms;      /* HOST_SAH: host wall time; DEVICE_LBVH: wall time of the launch sequence
+                               including its two small read-backs */
+  double grid_build_ms;     /* host wall time */
+  double upload_ms;         /* whole rtow_scene_upload call */
+} rtow_build_info_t;
+/* Facts about the last rtow_scene_upload of this context. */
+int rtow_build_info(rtow_ctx *ctx, rtow_build_info_t *out);
 
 /* Number of image rows owned by cfg->rank, and their global row numbers
  * (ascending) — pure host arithmetic, usable without a GPU. */

@@ -1,0 +1,417 @@
+// rtow_build.hip — device-side build of the BVH kernel's scene image.
+//
+// Replaces, for the device, what the reference does on the host in BVHNode's constructor
+// (src/render.cpp:73-110: recursive median split, one std::sort per level).  The device tree
+// is a linear BVH: Morton codes of the primitive centroids, one radix sort, Karras' binary
+// radix tree (every inner node found independently), a bottom-up pass that unions boxes and
+// counts subtree sizes, and an emit pass that writes the SAME threaded depth-first node
+// records the host builder (rtow_bvh.h) produces.  The closest hit does not depend on the
+// tree (rtow_bvh.h header), so images are bit-identical with either builder; what changes is
+// build time (one launch sequence of ~0.1 ms instead of a host SAH sweep) and tree quality.
+//
+// All kernels are index-checked against `n`; the emitted links are validated on the device
+// before the trace kernel may use the image (same rules as validate_scene_image()).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include <stdint.h>
+
+#include "rtow_device.h"
+
+namespace rtow {
+
+namespace {
+
+constexpr int kLeafBit = (int)0x80000000u;
+
+struct Scratch {
+  int n = 0;         // primitives of the current build
+  int capacity = 0;  // primitives the buffers can hold
+  float *pbox = nullptr;               // [n][6] padded f32 primitive boxes
+  double *pbox64 = nullptr;            // [n][6] exact f64 bounds
+  unsigned long long *keys_a = nullptr, *keys_b = nullptr;
+  uint32_t *vals_a = nullptr, *vals_b = nullptr;
+  int32_t *child_l = nullptr, *child_r = nullptr, *first = nullptr, *last = nullptr;
+  int32_t *parent_int = nullptr, *parent_leaf = nullptr;
+  float *ibox = nullptr;               // [n-1][6]
+  int32_t *size = nullptr;             // [n-1] emitted records in the subtree
+  uint32_t *flags = nullptr;           // [n-1] arrival counters; later: near-child-first bit
+  uint32_t *glob = nullptr;            // [8]: 0..2 centroid min, 3..5 centroid max (ordered u32), 6 scale bits, 7 error flag
+  void *sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+};
+
+__device__ __forceinline__ uint32_t ordered(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unordered(uint32_t o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// ---- pass 1: exact primitive bounds (f64), scene scale, centroid bounds -----------------
+__global__ void k_bounds(const double *sph, const double *sph_r, const double *mov, const double *tri, int ns,
+                         int nm, int nt, double time0, double time1, double *pbox64, uint32_t *glob) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = ns + nm + nt;
+  // scene-wide minima/maxima: LDS atomics per workgroup, then 7 global atomics per workgroup
+  __shared__ uint32_t sh[7];
+  if (threadIdx.x < 7) sh[threadIdx.x] = threadIdx.x < 3 ? 0xffffffffu : 0u;
+  __syncthreads();
+  if (i < n) {
+  double mn[3], mx[3];
+  if (i < ns) {
+    const double r = fabs(sph_r[i]);
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = sph[(size_t)i * 4 + k] - r;
+      mx[k] = sph[(size_t)i * 4 + k] + r;
+    }
+  } else if (i < ns + nm) {
+    // centre(time) = c0 + time*delta over the shutter interval, widened a little (rtow_bvh.h)
+    const double *m = mov + (size_t)(i - ns) * 8;
+    const double r = fabs(m[7]);
+    const double w = 1e-6 * (1.0 + fabs(time0) + fabs(time1));
+    const double ta = fmin(time0, time1) - w, tb = fmax(time0, time1) + w;
+    for (int k = 0; k < 3; ++k) {
+      const double a0 = m[k] + ta * m[3 + k], a1 = m[k] + tb * m[3 + k];
+      mn[k] = fmin(a0, a1) - r;
+      mx[k] = fmax(a0, a1) + r;
+    }
+  } else {
+    const double *t = tri + (size_t)(i - ns - nm) * 12;
+    for (int k = 0; k < 3; ++k) {
+      const double a = t[k], b = t[k] + t[3 + k], c = t[k] + t[6 + k];
+      mn[k] = fmin(a, fmin(b, c));
+      mx[k] = fmax(a, fmax(b, c));
+    }
+  }
+  float amax = 0.0f;
+  for (int k = 0; k < 3; ++k) {
+    // slack ≫ any rounding in a f64 slab test (pad_box in rtow_bvh.h)
+    const double ext = fmax(fabs(mn[k]), fabs(mx[k]));
+    const double pad = 1e-9 * (1.0 + ext);
+    mn[k] -= pad;
+    mx[k] += pad;
+    pbox64[(size_t)i * 6 + k] = mn[k];
+    pbox64[(size_t)i * 6 + 3 + k] = mx[k];
+    amax = fmaxf(amax, __double2float_ru(fmax(fabs(mn[k]), fabs(mx[k]))));
+    const double c = 0.5 * (mn[k] + mx[k]);
+    atomicMin(&sh[k], ordered(__double2float_rd(c)));
+    atomicMax(&sh[3 + k], ordered(__double2float_ru(c)));
+  }
+  atomicMax(&sh[6], __float_as_uint(amax));  // non-negative floats order like their bits
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicMin(&glob[threadIdx.x], sh[threadIdx.x]);
+  else if (threadIdx.x < 7) atomicMax(&glob[threadIdx.x], sh[threadIdx.x]);
+}
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {  // 21 bits -> every third bit
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+// ---- pass 2: padded f32 boxes (conservative for the f32 slab test) + 63-bit Morton keys ----
+__global__ void k_morton(const double *pbox64, int n, double cam_scale, const uint32_t *glob, float *pbox,
+                         unsigned long long *keys, uint32_t *vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // the f32 slab test sees the ray origin and the planes rounded to f32: pad every box by more
+  // than that rounding can move a plane or an origin anywhere in the scene (make_scene_image)
+  const double scale = fmax(fmax((double)__uint_as_float(glob[6]), cam_scale), 1.0);
+  unsigned long long key = 0;
+  for (int k = 0; k < 3; ++k) {
+    const double lo = pbox64[(size_t)i * 6 + k], hi = pbox64[(size_t)i * 6 + 3 + k];
+    const double pad = 2e-6 * scale + 2e-6 * fmax(fabs(lo), fabs(hi));
+    pbox[(size_t)i * 6 + k] = nextafterf(__double2float_rd(lo - pad), -INFINITY);
+    pbox[(size_t)i * 6 + 3 + k] = nextafterf(__double2float_ru(hi + pad), INFINITY);
+    const double cmin = (double)unordered(glob[k]), cmax = (double)unordered(glob[3 + k]);
+    const double ext = cmax - cmin;
+    const double c = 0.5 * (lo + hi);
+    double u = ext > 0.0 ? (c - cmin) / ext : 0.0;
+    u = fmin(fmax(u, 0.0), 1.0);
+    const unsigned long long q = (unsigned long long)fmin(u * 2097152.0, 2097151.0);
+    key |= spread21(q) << (2 - k);
+  }
+  keys[i] = key;
+  vals[i] = (uint32_t)i;
+}
+
+// ---- pass 3: Karras' binary radix tree over the sorted keys -------------------------------
+__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const unsigned long long a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((unsigned)(i ^ j));  // equal keys: the index breaks the tie
+  return __clzll((long long)(a ^ b));
+}
+
+__global__ void k_radix_tree(const unsigned long long *keys, int n, int32_t *child_l, int32_t *child_r,
+                             int32_t *first, int32_t *last, int32_t *parent_int, int32_t *parent_leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;  // i + lmax*d leaves [0,n) after <= log2(n)+1 doublings
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0, t = l;
+  do {
+    t = (t + 1) / 2;
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + (d < 0 ? -1 : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  const bool leaf_l = lo == gamma, leaf_r = hi == gamma + 1;
+  child_l[i] = leaf_l ? (gamma | kLeafBit) : gamma;
+  child_r[i] = leaf_r ? ((gamma + 1) | kLeafBit) : gamma + 1;
+  first[i] = lo;
+  last[i] = hi;
+  if (leaf_l) parent_leaf[gamma] = i; else parent_int[gamma] = i;
+  if (leaf_r) parent_leaf[gamma + 1] = i; else parent_int[gamma + 1] = i;
+  if (i == 0) parent_int[0] = -1;
+}
+
+// ---- pass 4: bottom-up boxes, emitted-subtree sizes, near-child-first bit ------------------
+__global__ void k_refit(int n, int leaf_max, const uint32_t *vals, const float *pbox, const int32_t *child_l,
+                        const int32_t *child_r, const int32_t *first, const int32_t *last,
+                        const int32_t *parent_int, const int32_t *parent_leaf, float cx, float cy, float cz,
+                        float *ibox, int32_t *size, uint32_t *flags) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int node = parent_leaf[p];
+  while (node >= 0) {
+    __threadfence();
+    const uint32_t old = atomicAdd(&flags[node], 1u);
+    if ((old & 3u) == 0u) return;  // first arrival: the sibling's thread finishes this node
+    __threadfence();
+    float b[2][6];
+    int sz[2];
+    const int32_t ch[2] = {child_l[node], child_r[node]};
+    for (int c = 0; c < 2; ++c) {
+      const int idx = ch[c] & 0x7fffffff;
+      const bool leaf = ch[c] < 0;
+      const float *src = leaf ? pbox + (size_t)vals[idx] * 6 : ibox + (size_t)idx * 6;
+      // written by another workgroup just before its arrival: read past this CU's L1
+      for (int k = 0; k < 6; ++k)
+        b[c][k] = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(src + k), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT));
+      sz[c] = leaf ? 1 : __hip_atomic_load(size + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float u[6];
+    for (int k = 0; k < 3; ++k) {
+      u[k] = fminf(b[0][k], b[1][k]);
+      u[3 + k] = fmaxf(b[0][k + 3], b[1][k + 3]);
+    }
+    for (int k = 0; k < 6; ++k) ibox[(size_t)node * 6 + k] = u[k];
+    const int count = last[node] - first[node] + 1;
+    size[node] = count <= leaf_max ? 1 : 1 + sz[0] + sz[1];
+    // the child whose box centre is nearer to the camera is numbered (and walked) first
+    float d2[2];
+    for (int c = 0; c < 2; ++c) {
+      const float mx = 0.5f * (b[c][0] + b[c][3]) - cx, my = 0.5f * (b[c][1] + b[c][4]) - cy,
+                  mz = 0.5f * (b[c][2] + b[c][5]) - cz;
+      d2[c] = mx * mx + my * my + mz * mz;
+    }
+    if (!(d2[0] <= d2[1])) atomicOr(&flags[node], 4u);  // bit 2: right child first
+    node = parent_int[node];
+  }
+}
+
+// ---- pass 5: emit the threaded depth-first node records + the id section -------------------
+// A record is emitted for: inner nodes covering > leaf_max primitives; the topmost nodes
+// covering <= leaf_max (as leaf records); single primitives whose parent is an inner record.
+__device__ __forceinline__ void write_node(unsigned char *blob, uint32_t idx, const float *box, uint32_t skip,
+                                           uint32_t leaf) {
+  float *dst = reinterpret_cast<float *>(blob + (size_t)idx * 32);
+  for (int k = 0; k < 6; ++k) dst[k] = box[k];
+  reinterpret_cast<uint32_t *>(dst)[6] = skip;
+  reinterpret_cast<uint32_t *>(dst)[7] = leaf;
+}
+
+__global__ void k_emit(int n, int leaf_max, const uint32_t *vals, const float *pbox, const int32_t *child_l,
+                       const int32_t *child_r, const int32_t *first, const int32_t *last,
+                       const int32_t *parent_int, const int32_t *parent_leaf, const float *ibox,
+                       const int32_t *size, const uint32_t *flags, unsigned char *blob, uint32_t off_ids,
+                       uint32_t n_nodes) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= 2 * n - 1) return;
+  const bool is_leaf = tid >= n - 1;
+  const int me = is_leaf ? tid - (n - 1) : tid;
+  if (is_leaf) reinterpret_cast<uint32_t *>(blob + off_ids)[me] = vals[me];
+  if (n == 1) {  // a single primitive: one leaf record
+    if (tid == 0) write_node(blob, 0u, pbox + (size_t)vals[0] * 6, 1u, (0u << 3) | 1u);
+  } else {
+    const int parent = is_leaf ? parent_leaf[me] : parent_int[me];
+    const int count = is_leaf ? 1 : last[me] - first[me] + 1;
+    const int pcount = parent < 0 ? 0x7fffffff : last[parent] - first[parent] + 1;
+    if (pcount > leaf_max) {  // otherwise this node sits inside a collapsed leaf
+      // preorder index: walk to the root, adding 1 per level + the first child's subtree where
+      // this path goes through the second child
+      uint32_t idx = 0;
+      int cur = is_leaf ? (me | kLeafBit) : me;
+      int par = parent;
+      while (par >= 0) {
+        const bool right_first = (flags[par] & 4u) != 0u;
+        const int32_t fc = right_first ? child_r[par] : child_l[par];
+        idx += 1u;
+        if (fc != cur) idx += fc < 0 ? 1u : (uint32_t)size[fc];
+        cur = par;
+        par = parent_int[par];
+      }
+      const float *box = is_leaf ? pbox + (size_t)vals[me] * 6 : ibox + (size_t)me * 6;
+      if (count > leaf_max) {
+        write_node(blob, idx, box, idx + (uint32_t)size[me], 0u);
+      } else {
+        const uint32_t f = is_leaf ? (uint32_t)me : (uint32_t)first[me];
+        write_node(blob, idx, box, idx + 1u, (f << 3) | (uint32_t)count);
+      }
+    }
+  }
+  if (tid == 0) {  // sentinel END record: skip link to itself, no leaf (rtow_bvh.h)
+    const float e[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    write_node(blob, n_nodes, e, n_nodes, 0u);
+  }
+}
+
+// ---- pass 6: the trace kernel's termination argument, checked on the device ----------------
+__global__ void k_validate(const unsigned char *blob, uint32_t n_nodes, uint32_t off_ids, int n_prims,
+                           uint32_t *err) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n_nodes) return;
+  const uint32_t *rec = reinterpret_cast<const uint32_t *>(blob + (size_t)i * 32);
+  const uint32_t skip = rec[6], leaf = rec[7];
+  bool ok = true;
+  if (i == n_nodes) {
+    ok = skip == n_nodes && leaf == 0u;
+  } else {
+    ok = skip > i && skip <= n_nodes;
+    if (leaf != 0u) {
+      const uint32_t f = leaf >> 3, c = leaf & 7u;
+      ok = ok && c != 0u && f + c <= (uint32_t)n_prims && skip == i + 1u;
+      if (ok)
+        for (uint32_t k = 0; k < c; ++k) {
+          const uint32_t id = reinterpret_cast<const uint32_t *>(blob + off_ids)[f + k];
+          ok = ok && id < (uint32_t)n_prims;
+        }
+    } else {
+      ok = ok && i + 1u < n_nodes;  // an inner node needs a child at i+1
+    }
+  }
+  if (!ok) atomicOr(err, 1u);
+}
+
+void release(Scratch *s) {
+  if (!s) return;
+  void *ptrs[] = {s->pbox,     s->pbox64,  s->keys_a,     s->keys_b,      s->vals_a, s->vals_b, s->child_l,
+                  s->child_r,  s->first,   s->last,       s->parent_int,  s->parent_leaf,
+                  s->ibox,     s->size,    s->flags,      s->glob,        s->sort_tmp};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  delete s;
+}
+
+template <class T>
+bool dev_alloc(T *&p, size_t count) {
+  return hipMalloc(reinterpret_cast<void **>(&p), (count ? count : 1) * sizeof(T)) == hipSuccess;
+}
+
+}  // namespace
+
+// Phase 1: builds the tree in scratch memory.  Returns 0 and the number of node records the
+// image will hold (without the END record).  `*handle` is the scratch: NULL on the first call,
+// reused (and grown when needed) by later builds, released with lbvh_release.
+int lbvh_build(const double *sph, const double *sph_r, const double *mov, const double *tri, int ns, int nm,
+               int nt, double time0, double time1, const double cam_origin[3], int leaf_max, void *stream,
+               void **handle, int *n_nodes) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int n = ns + nm + nt;
+  if (n <= 0 || leaf_max < 1 || leaf_max > 7) return 1;
+  Scratch *s = static_cast<Scratch *>(*handle);
+  const size_t ni = n > 1 ? (size_t)n - 1 : 1;
+  if (!s || s->capacity < n) {
+    release(s);
+    *handle = nullptr;
+    s = new Scratch;
+    const int cap = n + n / 8 + 64;
+    const size_t ci = (size_t)cap;
+    bool ok = dev_alloc(s->pbox, ci * 6) && dev_alloc(s->pbox64, ci * 6) && dev_alloc(s->keys_a, ci) &&
+              dev_alloc(s->keys_b, ci) && dev_alloc(s->vals_a, ci) && dev_alloc(s->vals_b, ci) &&
+              dev_alloc(s->child_l, ci) && dev_alloc(s->child_r, ci) && dev_alloc(s->first, ci) &&
+              dev_alloc(s->last, ci) && dev_alloc(s->parent_int, ci) && dev_alloc(s->parent_leaf, ci) &&
+              dev_alloc(s->ibox, ci * 6) && dev_alloc(s->size, ci) && dev_alloc(s->flags, ci) &&
+              dev_alloc(s->glob, 8);
+    if (ok) {
+      ok = hipcub::DeviceRadixSort::SortPairs(nullptr, s->sort_tmp_bytes, s->keys_a, s->keys_b, s->vals_a,
+                                              s->vals_b, cap, 0, 63, st) == hipSuccess &&
+           hipMalloc(&s->sort_tmp, s->sort_tmp_bytes ? s->sort_tmp_bytes : 16) == hipSuccess;
+    }
+    if (!ok) {
+      release(s);
+      return 2;
+    }
+    s->capacity = cap;
+    *handle = s;
+  }
+  s->n = n;
+  const uint32_t glob0[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+  const int B = 256, G = (n + B - 1) / B;
+  double cam_scale = 0.0;
+  for (int k = 0; k < 3; ++k) cam_scale = fmax(cam_scale, fabs(cam_origin[k]));
+  bool good = hipMemcpyAsync(s->glob, glob0, sizeof glob0, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemsetAsync(s->flags, 0, ni * sizeof(uint32_t), st) == hipSuccess;
+  if (good) {
+    hipLaunchKernelGGL(k_bounds, dim3(G), dim3(B), 0, st, sph, sph_r, mov, tri, ns, nm, nt, time0, time1,
+                       s->pbox64, s->glob);
+    hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, st, s->pbox64, n, cam_scale, s->glob, s->pbox, s->keys_a,
+                       s->vals_a);
+    size_t tmp_bytes = s->sort_tmp_bytes;
+    good = hipcub::DeviceRadixSort::SortPairs(s->sort_tmp, tmp_bytes, s->keys_a, s->keys_b, s->vals_a,
+                                              s->vals_b, n, 0, 63, st) == hipSuccess;
+  }
+  int32_t root_size = 1;
+  if (good && n > 1) {
+    hipLaunchKernelGGL(k_radix_tree, dim3(G), dim3(B), 0, st, s->keys_b, n, s->child_l, s->child_r, s->first,
+                       s->last, s->parent_int, s->parent_leaf);
+    hipLaunchKernelGGL(k_refit, dim3(G), dim3(B), 0, st, n, leaf_max, s->vals_b, s->pbox, s->child_l, s->child_r,
+                       s->first, s->last, s->parent_int, s->parent_leaf, (float)cam_origin[0],
+                       (float)cam_origin[1], (float)cam_origin[2], s->ibox, s->size, s->flags);
+    good = hipMemcpyAsync(&root_size, s->size, sizeof root_size, hipMemcpyDeviceToHost, st) == hipSuccess;
+  }
+  good = good && hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+  if (!good || root_size < 1 || root_size > 2 * n) return 3;
+  *n_nodes = root_size;
+  return 0;
+}
+
+// Phase 2: writes node records, END record and the id section into the device image (whose
+// record sections the caller fills), validates the links.
+int lbvh_emit(void *handle, int leaf_max, unsigned char *blob_dev, uint32_t off_ids, int n_nodes, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Scratch *s = static_cast<Scratch *>(handle);
+  if (!s) return 1;
+  const int n = s->n;
+  const int B = 256;
+  hipLaunchKernelGGL(k_emit, dim3((2 * n - 1 + B - 1) / B), dim3(B), 0, st, n, leaf_max, s->vals_b, s->pbox,
+                     s->child_l, s->child_r, s->first, s->last, s->parent_int, s->parent_leaf, s->ibox, s->size,
+                     s->flags, blob_dev, off_ids, (uint32_t)n_nodes);
+  hipLaunchKernelGGL(k_validate, dim3((n_nodes + 1 + B - 1) / B), dim3(B), 0, st, blob_dev, (uint32_t)n_nodes,
+                     off_ids, n, s->glob + 7);
+  uint32_t err = 1;
+  const bool good = hipMemcpyAsync(&err, s->glob + 7, sizeof err, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                    hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+  if (!good) return 3;
+  return err ? 4 : 0;
+}
+
+void lbvh_release(void *handle) { release(static_cast<Scratch *>(handle)); }
+
+}  // namespace rtow

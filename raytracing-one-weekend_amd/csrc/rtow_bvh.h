@@ -259,7 +259,37 @@ struct SceneImage {
   uint32_t off_ids = 0, off_sph = 0, off_mov = 0, off_tri = 0;
   uint32_t off_pmat = 0, off_mats = 0;  // material index per primitive, material records
   int32_t n_nodes = 0;
+  size_t total_bytes = 0;
 };
+
+// Section offsets and everything but the node records and the id list: zeroed node section for
+// n_nodes records + the END record, primitive records, material index per primitive, materials.
+// (The device builder, rtow_build.hip, fills nodes and ids in HBM.)
+inline void layout_scene_image(int n_nodes, size_t n_ids, const std::vector<double> &sph,
+                               const std::vector<double> &mov, const std::vector<double> &tri,
+                               const std::vector<int32_t> &prim_mat,
+                               const std::vector<unsigned char> &mats_bytes, SceneImage &img,
+                               bool offsets_only = false) {
+  const size_t nodes_bytes = (size_t)(n_nodes + 1) * 32;  // + the sentinel END node
+  const size_t ids_bytes = ((n_ids * 4 + 15) / 16) * 16;
+  img.off_ids = (uint32_t)nodes_bytes;
+  img.off_sph = (uint32_t)(nodes_bytes + ids_bytes);
+  img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
+  img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
+  img.off_pmat = (uint32_t)((((size_t)img.off_tri + tri.size() * 8) + 15) / 16 * 16);
+  img.off_mats = (uint32_t)((((size_t)img.off_pmat + prim_mat.size() * 4) + 15) / 16 * 16);
+  const size_t total = (size_t)img.off_mats + mats_bytes.size();
+  img.total_bytes = ((total + 15) / 16) * 16;
+  img.n_nodes = n_nodes;
+  if (offsets_only) return;  // the device builder assembles the image in HBM
+  img.blob.assign(img.total_bytes, 0);
+  if (!prim_mat.empty()) std::memcpy(img.blob.data() + img.off_pmat, prim_mat.data(), prim_mat.size() * 4);
+  if (!mats_bytes.empty()) std::memcpy(img.blob.data() + img.off_mats, mats_bytes.data(), mats_bytes.size());
+  if (!sph.empty()) std::memcpy(img.blob.data() + img.off_sph, sph.data(), sph.size() * 8);
+  if (!mov.empty()) std::memcpy(img.blob.data() + img.off_mov, mov.data(), mov.size() * 8);
+  if (!tri.empty()) std::memcpy(img.blob.data() + img.off_tri, tri.data(), tri.size() * 8);
+  img.n_nodes = n_nodes;
+}
 
 inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
                              const std::vector<double> &mov, const std::vector<double> &tri,
@@ -315,19 +345,7 @@ inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
       size[i] = 1 + size[newidx[l]] + size[newidx[l + 1]];
     }
   }
-  const size_t nodes_bytes = (size_t)(n + 1) * 32;  // + the sentinel END node
-  const size_t ids_bytes = ((bvh.prim.size() * 4 + 15) / 16) * 16;
-  img.off_ids = (uint32_t)nodes_bytes;
-  img.off_sph = (uint32_t)(nodes_bytes + ids_bytes);
-  img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
-  img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
-  img.off_pmat = (uint32_t)((((size_t)img.off_tri + tri.size() * 8) + 15) / 16 * 16);
-  img.off_mats = (uint32_t)((((size_t)img.off_pmat + prim_mat.size() * 4) + 15) / 16 * 16);
-  const size_t total = (size_t)img.off_mats + mats_bytes.size();
-  img.blob.assign(((total + 15) / 16) * 16, 0);
-  if (!prim_mat.empty()) std::memcpy(img.blob.data() + img.off_pmat, prim_mat.data(), prim_mat.size() * 4);
-  if (!mats_bytes.empty()) std::memcpy(img.blob.data() + img.off_mats, mats_bytes.data(), mats_bytes.size());
-  img.n_nodes = n;
+  layout_scene_image(n, bvh.prim.size(), sph, mov, tri, prim_mat, mats_bytes, img);
   for (int i = 0; i < n; ++i) {
     const int nd = order[i];
     float rec[6];
@@ -356,9 +374,6 @@ inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
     std::memcpy(dst + 28, &leaf, 4);
   }
   if (!bvh.prim.empty()) std::memcpy(img.blob.data() + img.off_ids, bvh.prim.data(), bvh.prim.size() * 4);
-  if (!sph.empty()) std::memcpy(img.blob.data() + img.off_sph, sph.data(), sph.size() * 8);
-  if (!mov.empty()) std::memcpy(img.blob.data() + img.off_mov, mov.data(), mov.size() * 8);
-  if (!tri.empty()) std::memcpy(img.blob.data() + img.off_tri, tri.data(), tri.size() * 8);
 }
 
 // The kernel's termination argument rests on these: every skip link points forward and

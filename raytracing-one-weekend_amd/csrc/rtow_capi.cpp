@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -104,7 +105,20 @@ int upload(DevBuf &b, const std::vector<T> &v) {
   return RTOW_OK;
 }
 
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
 }  // namespace
+
+namespace rtow {  // csrc/rtow_build.hip
+int lbvh_build(const double *sph, const double *sph_r, const double *mov, const double *tri, int ns, int nm,
+               int nt, double time0, double time1, const double cam_origin[3], int leaf_max, void *stream,
+               void **handle, int *n_nodes);
+int lbvh_emit(void *handle, int leaf_max, unsigned char *blob_dev, uint32_t off_ids, int n_nodes, void *stream);
+void lbvh_release(void *handle);
+}  // namespace rtow
 
 struct rtow_ctx {
   int device = 0;
@@ -119,6 +133,9 @@ struct rtow_ctx {
   bool have_grid = false;
   uint32_t blob_bytes = 0;
   long long bvh_nodes = 0;
+  int builder = RTOW_BUILDER_HOST_SAH;
+  void *lbvh_scratch = nullptr;  // device builder's buffers, kept across uploads
+  rtow_build_info_t build_info{};
   // workspace
   DevBuf partials, stack, counters;
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
@@ -152,6 +169,8 @@ int rtow_ctx_create(int device_id, rtow_ctx **out) {
   rtow_ctx *c = new rtow_ctx();
   c->device = device_id;
   c->num_cus = prop.multiProcessorCount;
+  if (const char *e = std::getenv("RTOW_BUILDER"))
+    c->builder = std::strcmp(e, "device") == 0 ? RTOW_BUILDER_DEVICE_LBVH : RTOW_BUILDER_HOST_SAH;
   for (int i = 0; i < kEventRing; ++i)
     for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreate(&c->ev[i][k]));
   for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreate(&c->call_ev[k]));
@@ -174,6 +193,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
     for (int k = 0; k < 2; ++k) (void)hipEventDestroy(c->call_ev[k]);
   }
   if (c->h_counters) (void)hipHostFree(c->h_counters);
+  rtow::lbvh_release(c->lbvh_scratch);
   delete c;
 }
 
@@ -210,6 +230,7 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipDeviceSynchronize());
   c->have_scene = false;
+  const double t_up0 = now_ms();
 
   // Ray-independent terms, computed with the reference's operations (this file is
   // built with -ffp-contract=off, so each is one IEEE operation, as on the CPU).
@@ -270,25 +291,51 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     d.kind = m.kind;
   }
 
-  // device BVH over the same records, packed with them into one scene image
-  rtow::HostBvh bvh;
-  int leaf_max = 4;
-  if (const char *e = std::getenv("RTOW_BVH_LEAF")) leaf_max = std::atoi(e);
-  double c_trav = 0.0;
-  if (const char *e = std::getenv("RTOW_BVH_CT")) c_trav = std::atof(e);
-  rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
+  // BVH over the same records, packed with them into one scene image
+  // host SAH stops splitting by cost (mostly 1-2 primitives per leaf, cap 4); the radix tree has
+  // no cost model, so its leaves are capped at 2 (measured: 1 and 2 equal, 4 is 8-17 % slower)
+  int leaf_max = c->builder == RTOW_BUILDER_DEVICE_LBVH ? 2 : 4;
+  if (const char *e = std::getenv("RTOW_BVH_LEAF")) leaf_max = std::min(std::max(std::atoi(e), 1), 7);
   rtow::SceneImage img;
   std::vector<unsigned char> mats_bytes(mats.size() * sizeof(rtow::DevMaterial));
   std::memcpy(mats_bytes.data(), mats.data(), mats_bytes.size());
-  rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img, pmat, mats_bytes);
-  if (!rtow::validate_scene_image(img, ns + nm + nt))
-    return fail(RTOW_EINVAL, "internal error: scene image failed validation (BVH links)");
-
   if ((rc = upload(c->sph, sph)) || (rc = upload(c->sph_r, sph_r)) || (rc = upload(c->mov, mov)) ||
-      (rc = upload(c->tri, tri)) || (rc = upload(c->prim_mat, pmat)) || (rc = upload(c->mats, mats)) ||
-      (rc = upload(c->blob, img.blob)))
+      (rc = upload(c->tri, tri)) || (rc = upload(c->prim_mat, pmat)) || (rc = upload(c->mats, mats)))
     return rc;
-  c->blob_bytes = (uint32_t)img.blob.size();
+  const double t_bvh0 = now_ms();
+  if (c->builder == RTOW_BUILDER_DEVICE_LBVH) {
+    // the tree is built in HBM from the record arrays just uploaded; the host only lays out
+    // the image sections around it
+    int n_nodes = 0;
+    int brc = rtow::lbvh_build((const double *)c->sph.p, (const double *)c->sph_r.p, (const double *)c->mov.p,
+                               (const double *)c->tri.p, ns, nm, nt, s->camera.t0, s->camera.t1, s->camera.origin,
+                               leaf_max, nullptr, &c->lbvh_scratch, &n_nodes);
+    if (brc) return fail(RTOW_EHIP, "device BVH build failed (stage %d): %s", brc, hipGetErrorString(hipGetLastError()));
+    rtow::layout_scene_image(n_nodes, (size_t)(ns + nm + nt), sph, mov, tri, pmat, mats_bytes, img, true);
+    if ((rc = c->blob.ensure(img.total_bytes))) return rc;
+    // image sections: device-to-device copies of the arrays uploaded above, zeroed node section
+    unsigned char *bp = (unsigned char *)c->blob.p;
+    HIPCHK(hipMemsetAsync(bp, 0, img.off_sph, nullptr));
+    if (ns) HIPCHK(hipMemcpyAsync(bp + img.off_sph, c->sph.p, sph.size() * 8, hipMemcpyDeviceToDevice, nullptr));
+    if (nm) HIPCHK(hipMemcpyAsync(bp + img.off_mov, c->mov.p, mov.size() * 8, hipMemcpyDeviceToDevice, nullptr));
+    if (nt) HIPCHK(hipMemcpyAsync(bp + img.off_tri, c->tri.p, tri.size() * 8, hipMemcpyDeviceToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(bp + img.off_pmat, c->prim_mat.p, pmat.size() * 4, hipMemcpyDeviceToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(bp + img.off_mats, c->mats.p, mats_bytes.size(), hipMemcpyDeviceToDevice, nullptr));
+    brc = rtow::lbvh_emit(c->lbvh_scratch, leaf_max, bp, img.off_ids, n_nodes, nullptr);
+    if (brc == 4) return fail(RTOW_EINVAL, "internal error: device-built scene image failed validation (BVH links)");
+    if (brc) return fail(RTOW_EHIP, "device BVH emit failed (stage %d): %s", brc, hipGetErrorString(hipGetLastError()));
+  } else {
+    rtow::HostBvh bvh;
+    double c_trav = 0.0;
+    if (const char *e = std::getenv("RTOW_BVH_CT")) c_trav = std::atof(e);
+    rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
+    rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img, pmat, mats_bytes);
+    if (!rtow::validate_scene_image(img, ns + nm + nt))
+      return fail(RTOW_EINVAL, "internal error: scene image failed validation (BVH links)");
+    if ((rc = upload(c->blob, img.blob))) return rc;
+  }
+  const double t_bvh1 = now_ms();
+  c->blob_bytes = (uint32_t)img.total_bytes;
   c->bvh_nodes = img.n_nodes;
   // uniform grid over the small primitives (when the scene suits it)
   rtow::GridImage gimg;
@@ -296,8 +343,14 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   if (const char *e = std::getenv("RTOW_GRID_CPP")) cpp = std::atof(e);
   double large_ratio = 4.0;
   if (const char *e = std::getenv("RTOW_GRID_LARGE")) large_ratio = std::atof(e);
-  rtow::build_grid_image(sph, sph_r, mov, tri, s->camera.origin, gimg, cpp, large_ratio, s->camera.t0,
-                         s->camera.t1, pmat, mats_bytes);
+  // big meshes never take the grid (a triangle spans many cells: 0.4x the BVH):
+  // skip the host build, a GRID request then falls back to the BVH
+  int grid_max_tris = 8192;
+  if (const char *e = std::getenv("RTOW_GRID_MAX_TRIS")) grid_max_tris = std::atoi(e);
+  if (nt <= grid_max_tris)
+    rtow::build_grid_image(sph, sph_r, mov, tri, s->camera.origin, gimg, cpp, large_ratio, s->camera.t0,
+                           s->camera.t1, pmat, mats_bytes);
+  const double t_grid1 = now_ms();
   c->have_grid = gimg.ok;
   c->gblob_bytes = 0;
   if (gimg.ok) {
@@ -355,6 +408,14 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     if ((rc = upload(c->cam_dev, one))) return rc;
   }
   c->have_scene = true;
+  rtow_build_info_t &bi = c->build_info;
+  bi.builder = c->builder;
+  bi.bvh_nodes = (int32_t)img.n_nodes;
+  bi.bvh_image_bytes = (int32_t)c->blob_bytes;
+  bi.grid_image_bytes = (int32_t)c->gblob_bytes;
+  bi.bvh_build_ms = t_bvh1 - t_bvh0;
+  bi.grid_build_ms = t_grid1 - t_bvh1;
+  bi.upload_ms = now_ms() - t_up0;
   return RTOW_OK;
 }
 
@@ -379,6 +440,21 @@ static int validate_cfg(const rtow_config_t *cfg) {
       (cfg->stream_count == 0 && cfg->stream_first != 0))
     return fail(RTOW_EINVAL, "stream range [%d, %d+%d) outside [0, %d)", cfg->stream_first, cfg->stream_first,
                 cfg->stream_count, cfg->nstreams);
+  return RTOW_OK;
+}
+
+int rtow_ctx_set_builder(rtow_ctx *c, int32_t builder) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  if (builder != RTOW_BUILDER_HOST_SAH && builder != RTOW_BUILDER_DEVICE_LBVH)
+    return fail(RTOW_EINVAL, "unknown builder %d", builder);
+  c->builder = builder;
+  return RTOW_OK;
+}
+
+int rtow_build_info(rtow_ctx *c, rtow_build_info_t *out) {
+  if (!c || !out) return fail(RTOW_EINVAL, "NULL argument");
+  if (!c->have_scene) return fail(RTOW_EINVAL, "no scene uploaded");
+  *out = c->build_info;
   return RTOW_OK;
 }
 

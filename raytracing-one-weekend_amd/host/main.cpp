@@ -31,6 +31,7 @@ static void usage(const char *argv0) {
                "  --seed UINT                 render seed of the counter-based RNG (default 1)\n"
                "  --precision strict|fast     f64 without / with FMA contraction (default fast)\n"
                "  --kernel auto|brute|bvh|grid  closest-hit strategy (default auto)\n"
+               "  --builder host|device       BVH build: host SAH (default) or on the GPU (LBVH)\n"
                "  --p6                        binary P6 output, write_color on the device\n";
 }
 
@@ -83,6 +84,11 @@ int main(int argc, char *argv[]) {
         else throw std::runtime_error("--precision: strict|fast");
       } else if (std::strcmp(a, "--p6") == 0) {
         opt.binary_ppm = true;
+      } else if (std::strcmp(a, "--builder") == 0) {
+        const std::string v = value();
+        if (v == "host") opt.builder = 0;
+        else if (v == "device") opt.builder = 1;
+        else throw std::runtime_error("--builder: host|device");
       } else if (std::strcmp(a, "--kernel") == 0) {
         const std::string v = value();
         if (v == "auto") opt.kernel = 0;

@@ -222,10 +222,14 @@ void render(const Scene &world, const Config &cfg) {
   rtow_ctx *ctx = nullptr;
   rtow_stats_t st;
   int err = rtow_ctx_create(opt.device, &ctx);
+  if (err == RTOW_OK && opt.builder >= 0) err = rtow_ctx_set_builder(ctx, opt.builder);
+  rtow_build_info_t bi;
+  std::memset(&bi, 0, sizeof bi);
   if (err == RTOW_OK)
     err = opt.binary_ppm ? rtow_render_rgb8(ctx, flat_view(flat), &rc, rgb8.data(), &st)
                          : rtow_render(ctx, flat_view(flat), &rc, image.data(), &st);
   std::string msg = err == RTOW_OK ? "" : rtow_last_error();
+  if (err == RTOW_OK) (void)rtow_build_info(ctx, &bi);
   rtow_ctx_destroy(ctx);
   flat_free(flat);
   if (err != RTOW_OK) throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + msg);
@@ -239,6 +243,9 @@ void render(const Scene &world, const Config &cfg) {
   }
 
   auto took = khr::high_resolution_clock::now() - start;
+  std::cerr << "BVH image: " << bi.bvh_nodes << " nodes, " << bi.bvh_image_bytes << " bytes, built on the "
+            << (bi.builder == RTOW_BUILDER_DEVICE_LBVH ? "device (LBVH)" : "host (SAH)") << " in " << bi.bvh_build_ms
+            << " ms\n";
   std::cerr << "Traced " << st.samples << " samples, " << st.segments << " ray segments; kernel "
             << st.kernel_ms << " ms ("
             << (st.kernel_ms > 0 ? st.samples / st.kernel_ms / 1e3 : 0.0) << " Msamples/s)\n";

@@ -29,6 +29,7 @@ struct DeviceOptions {
   uint64_t seed = 1;
   int precision = 1;  // RTOW_F64_FAST; 0 = RTOW_F64_STRICT
   int kernel = 0;     // RTOW_KERNEL_AUTO
+  int builder = -1;   // -1: the context's default (RTOW_BUILDER env); 0 host SAH, 1 device LBVH
   bool binary_ppm = false;  // P6 (write_color runs on the device) instead of the reference's P3 text
 };
 DeviceOptions &device_options();

@@ -17,12 +17,13 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 LIB_PATH = Path(os.environ.get("RTOW_LIB", PKG_DIR / "librtow.so"))  # RTOW_LIB: A/B against another build
 
-RTOW_ABI_VERSION = 2
+RTOW_ABI_VERSION = 3
 RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY = 0, -1, -2, -3, -4, -5
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
 F64_STRICT, F64_FAST = 0, 1
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH, KERNEL_GRID = 0, 1, 2, 3
+BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1
 
 d3 = C.c_double * 3
 _pd = C.POINTER(C.c_double)
@@ -76,6 +77,14 @@ class Stats(C.Structure):
     ]
 
 
+class BuildInfo(C.Structure):
+    _fields_ = [
+        ("builder", C.c_int32), ("bvh_nodes", C.c_int32),
+        ("bvh_image_bytes", C.c_int32), ("grid_image_bytes", C.c_int32),
+        ("bvh_build_ms", C.c_double), ("grid_build_ms", C.c_double), ("upload_ms", C.c_double),
+    ]
+
+
 class HostConfig(C.Structure):
     _fields_ = [
         ("number_of_balls_sqrt", C.c_int32), ("aspect_ratio", C.c_double),
@@ -90,6 +99,7 @@ EXPORTS = [
     "rtow_render", "rtow_host_scene_cover", "rtow_host_scene_obj", "rtow_host_scene_free",
     "rtow_host_rng_reset", "rtow_host_ppm", "rtow_host_free", "rtow_tonemap_device",
     "rtow_profile_collect", "rtow_debug_counters", "rtow_render_rgb8",
+    "rtow_ctx_set_builder", "rtow_build_info",
 ]
 
 
@@ -132,6 +142,8 @@ def lib():
     L.rtow_host_free.argtypes = [C.c_void_p]
     L.rtow_host_free.restype = None
     L.rtow_tonemap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    L.rtow_ctx_set_builder.argtypes = [C.c_void_p, C.c_int32]
+    L.rtow_build_info.argtypes = [C.c_void_p, C.POINTER(BuildInfo)]
     if L.rtow_abi_version() != RTOW_ABI_VERSION:
         raise RtowError("librtow.so ABI version mismatch")
     _lib = L
@@ -244,6 +256,15 @@ class Context:
     def upload(self, scene):
         s = scene.c if isinstance(scene, HostScene) else scene
         check(lib().rtow_scene_upload(self._h, C.byref(s)), "rtow_scene_upload")
+
+    def set_builder(self, builder: int):
+        """BUILDER_HOST_SAH (default) or BUILDER_DEVICE_LBVH; applies from the next upload."""
+        check(lib().rtow_ctx_set_builder(self._h, builder), "rtow_ctx_set_builder")
+
+    def build_info(self) -> BuildInfo:
+        bi = BuildInfo()
+        check(lib().rtow_build_info(self._h, C.byref(bi)), "rtow_build_info")
+        return bi
 
     def render_device(self, cfg: Config, d_ptr: int, stream: int = 0, want_stats=False):
         st = Stats() if want_stats else None
