@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--no-scaling-base", action="store_true",
+                    help="N=1: skip the extra configs[2] (500 spp) measurement on this GPU")
     ap.add_argument("--precision", choices=["fast", "strict"], default="fast")
     ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid"], default="auto")
     ap.add_argument("--moving", action="store_true", help="moving-sphere variant of the cover scene")
@@ -285,6 +287,22 @@ def main():
                 "model": fmodel,
             },
         }
+        if world == 1 and spp == 100 and not a.no_scaling_base:
+            # like-for-like base of the N>1 lines (configs[2], 500 spp): the same frame on this one
+            # GPU, measured after the timed region (a longer launch amortises the end-of-launch tail)
+            cfg5 = rtow.make_config(W, H, 500, 500 // SAMPLES_PER_ITEM, DEPTH, seed=SEED, precision=precision, kernel=kernel)
+            ctx.render_device(cfg5, local.data_ptr(), stream.cuda_stream, True)
+            torch.cuda.synchronize(dev)
+            t5 = time.perf_counter()
+            for _ in range(3):
+                ctx.render_device(cfg5, local.data_ptr(), stream.cuda_stream, False)
+            torch.cuda.synchronize(dev)
+            e5 = (time.perf_counter() - t5) / 3
+            out["scaling_base"] = {
+                "workload": f"configs[2] on one GPU: {W}x{H}, 500 spp, {DEPTH} bounces (no gather)",
+                "value": round(W * H * 500 / e5 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(e5 * 1e3, 4),
+                "steps": 3,
+            }
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, H, a.cpu_seconds)
         else:

@@ -651,12 +651,12 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
 
 // Diagnostic: the 16 device counters of the last launch (work queue, segments, prim
 // tests, node tests, ... region cycle sums of the RTOW_STAMPS build at [8..12]).
-int rtow_debug_counters(rtow_ctx *c, unsigned long long *out16) {
-  if (!c || !out16) return fail(RTOW_EINVAL, "NULL argument");
+int rtow_debug_counters(rtow_ctx *c, unsigned long long *out24) {
+  if (!c || !out24) return fail(RTOW_EINVAL, "NULL argument");
   if (!c->counters.p) return fail(RTOW_ENOSCENE, "no launch yet");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out16, c->counters.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out24, c->counters.p, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RTOW_OK;
 }
 

@@ -15,7 +15,7 @@ else:
     cfg = rtow.make_config(1200, 800, 100, int(os.environ.get('RTOW_NSTREAMS', '10')), 50, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
 ctx = rtow.Context(0)
 img, st = ctx.render(scene, cfg)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 L = rtow.lib(); L.rtow_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 rtow.check(L.rtow_debug_counters(ctx._h, out))
 names = ["fetch", "regen", "walk-steps", "shade", "walk-leaves"]
@@ -29,3 +29,5 @@ print(f"wave trips {trips}, step-loop iterations per trip {iters/max(trips,1):.1
       f"lane-segments per trip {st.segments/max(trips,1):.1f} of 64")
 nw = 4096.0
 print(f"wave end times (ms after first wave start): mean {out[4]/nw/1e5:.3f}  min {out[5]/1e5:.3f}  max {out[6]/1e5:.3f};  queue seen empty (mean over waves) {out[7]/nw/1e5:.3f}")
+
+print("waves by (end - own queue-empty time), 0.2 ms bins [0-0.2, .., 0.8-1.0, >=1.0]:", [int(out[17 + i]) for i in range(6)])
