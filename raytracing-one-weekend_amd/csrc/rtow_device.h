@@ -48,11 +48,14 @@ struct DevScene {
   uint32_t blob_bytes;
   uint32_t off_ids, off_sph, off_mov, off_tri;
   uint32_t off_pmat, off_mats;  // shading data inside the image: prim -> material, material records
+  uint32_t off_sph32, off_mov32; // f32 build's image: binary32 sphere records (16 B / 32 B); its off_tri
+                                 // points at binary32 triangle records (48 B)
   int32_t n_nodes;
   // scene image for the GRID kernel (rtow_grid.h): header, cells, ids, records
   const unsigned char *gblob;
   uint32_t gblob_bytes;
   uint32_t g_off_cells, g_off_ids, g_off_sph, g_off_mov, g_off_tri, g_off_pmat, g_off_mats;
+  uint32_t g_off_sph32, g_off_mov32;
 };
 
 struct FastDiv {  // unsigned division by a per-launch constant (see fastdiv() in the kernel)
@@ -62,6 +65,7 @@ struct FastDiv {  // unsigned division by a per-launch constant (see fastdiv() i
 struct TraceParams {
   DevScene sc;
   const DevCamera *cam;    // in device memory: read with scalar loads where rays are generated
+  const float *cam32;      // the same 21 values as binary32 (f32 build)
                            // (by value it pinned 42 SGPRs across the whole kernel)
   int32_t W, H;            // full image
   int32_t spt;             // samples per stream (= spp / nstreams)
@@ -101,8 +105,11 @@ int launch_trace_strict(const TraceParams &p, int kernel, int grid, int block, u
                         void *stream);
 int launch_trace_fast(const TraceParams &p, int kernel, int grid, int block, unsigned lds_bytes,
                       void *stream);
+int launch_trace_f32(const TraceParams &p, int kernel, int grid, int block, unsigned lds_bytes,
+                     void *stream);
 int trace_occupancy_strict(int kernel, int block, unsigned lds_bytes);
 int trace_occupancy_fast(int kernel, int block, unsigned lds_bytes);
+int trace_occupancy_f32(int kernel, int block, unsigned lds_bytes);
 int launch_reduce(const ReduceParams &p, void *stream);
 int launch_tonemap(const double *sums, unsigned char *rgb8, uint32_t n, double spp, void *stream);
 

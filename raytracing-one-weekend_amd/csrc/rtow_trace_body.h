@@ -63,21 +63,45 @@ namespace {
 #define RTOW_CONST __attribute__((address_space(4)))
 typedef const RTOW_CONST double *cdptr;
 
-struct V3 {
-  double x, y, z;
+// Arithmetic type of rays, hit tests on small primitives and shading.  binary64 (the
+// reference's type) in the strict and fast builds; binary32 in the f32 build
+// (rtow_trace_f32.hip), where the always-test large primitives and all spheres met by the
+// STREAM/BVH kernels are still tested in binary64 (an r = 1000 sphere cancels catastrophically
+// in binary32: SURVEY.md §7 "fp32 robustness") and pixel sums stay binary64.
+#ifdef RTOW_REAL_F32
+typedef float real;
+#else
+typedef double real;
+#endif
+
+template <class T>
+struct Vec3 {
+  T x, y, z;
 };
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
-__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-__device__ __forceinline__ V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+typedef Vec3<real> V3;
+typedef Vec3<double> V3d;
+template <class T>
+__device__ __forceinline__ Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator-(Vec3<T> a, Vec3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator-(Vec3<T> a) { return {-a.x, -a.y, -a.z}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator*(Vec3<T> a, Vec3<T> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator*(Vec3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator*(T s, Vec3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
 // glm: dot = x*x' + y*y' + z*z' (left to right); cross, normalize (v * 1/sqrt),
 // reflect (I - N*dot(N,I)*2), refract — same definitions as oracle/rtow_oracle.cpp.
-__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 x, V3 y) {
+template <class T>
+__device__ __forceinline__ T dot(Vec3<T> a, Vec3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T>
+__device__ __forceinline__ Vec3<T> cross(Vec3<T> x, Vec3<T> y) {
   return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
 }
+__device__ __forceinline__ V3d to_f64(Vec3<float> v) { return {(double)v.x, (double)v.y, (double)v.z}; }
+__device__ __forceinline__ V3d to_f64(V3d v) { return v; }
 #ifdef RTOW_FAST_MATH
 // fast build: hardware reciprocal-square-root seed (~2^-26) + two Newton steps instead of the
 // correctly rounded sqrt and division (relative error ~1e-16; the strict build keeps IEEE forms)
@@ -95,21 +119,34 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return y;
 }
 __device__ __forceinline__ double fast_div(double n, double d) { return n * fast_rcp(d); }
-__device__ __forceinline__ V3 normalize(V3 v) { return v * fast_rsqrt(dot(v, v)); }
 #else
 __device__ __forceinline__ double fast_div(double n, double d) { return n / d; }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
-__device__ __forceinline__ V3 normalize(V3 v) { return v * (1.0 / sqrt(dot(v, v))); }
+__device__ __forceinline__ double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
 #endif
-__device__ __forceinline__ V3 reflect(V3 I, V3 N) { return I - N * dot(N, I) * 2.0; }
-__device__ __forceinline__ V3 refract(V3 I, V3 N, double eta) {
-  double d = dot(N, I);
-  double k = 1.0 - eta * eta * (1.0 - d * d);
-  if (k >= 0.0) return eta * I - (eta * d + fast_sqrt(k)) * N;
-  return {0.0, 0.0, 0.0};
+// binary32 forms (f32 build only): hardware rsq/rcp/sqrt (1 ulp) + one Newton step where it is cheap
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  return y * (1.5f - 0.5f * x * y * y);
 }
-__device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ float fast_sqrt(float x) { return x > 0.0f ? __builtin_amdgcn_sqrtf(x) : 0.0f; }
+__device__ __forceinline__ float fast_rcp(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  return y * (2.0f - x * y);
+}
+__device__ __forceinline__ float fast_div(float n, float d) { return n * fast_rcp(d); }
+template <class T>
+__device__ __forceinline__ Vec3<T> normalize(Vec3<T> v) { return v * fast_rsqrt(dot(v, v)); }
+template <class T>
+__device__ __forceinline__ Vec3<T> reflect(Vec3<T> I, Vec3<T> N) { return I - N * dot(N, I) * T(2.0); }
+template <class T>
+__device__ __forceinline__ Vec3<T> refract(Vec3<T> I, Vec3<T> N, T eta) {
+  T d = dot(N, I);
+  T k = T(1.0) - eta * eta * (T(1.0) - d * d);
+  if (k >= T(0.0)) return eta * I - (eta * d + fast_sqrt(k)) * N;
+  return {T(0.0), T(0.0), T(0.0)};
+}
 
 // ------------------------------------------------------------------ Philox ---
 struct Rng {
@@ -154,38 +191,54 @@ __device__ __forceinline__ double canonical_from_words(uint32_t w0, uint32_t w1)
 
 // One request = one block (w0..w3); see oracle/rtow_oracle.cpp, struct PhiloxDraw.
 // jitter + shutter time: 42 bits each (word k + 10 bits of word 3)
-__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, double &u, double &v,
-                                           double &t) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
+__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, double &u,
+                                                  double &v, double &t) {
   const double s42 = 0x1p-42;
   u = ((double)o0 + (double)(o3 & 1023u) * 4294967296.0) * s42;
   v = ((double)o1 + (double)((o3 >> 10) & 1023u) * 4294967296.0) * s42;
   t = ((double)o2 + (double)((o3 >> 20) & 1023u) * 4294967296.0) * s42;
 }
-// disk candidate: two doubles, each from two words like the reference's doubles
-__device__ __forceinline__ void rng_disk(Rng &g, uint32_t k0, uint32_t k1, double &a, double &b) {
+// binary32 build: the same blocks, 32 bits per value (a value that rounds up to 1.0 is harmless:
+// it moves a sample by one ulp of the pixel grid, and a rejection candidate at 1.0 is rejected)
+__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t, float &u,
+                                                  float &v, float &t) {
+  u = (float)o0 * 0x1p-32f;
+  v = (float)o1 * 0x1p-32f;
+  t = (float)o2 * 0x1p-32f;
+}
+__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, real &u, real &v, real &t) {
   uint32_t o0, o1, o2, o3;
   philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
+  jitter_from_block(o0, o1, o2, o3, u, v, t);
+}
+// disk candidate: two doubles, each from two words like the reference's doubles
+__device__ __forceinline__ void rng_disk(Rng &g, uint32_t k0, uint32_t k1, real &a, real &b) {
+  uint32_t o0, o1, o2, o3;
+  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
+#ifdef RTOW_REAL_F32
+  a = (float)o1 * 0x1p-32f;  // the high words of the two doubles
+  b = (float)o3 * 0x1p-32f;
+#else
   a = canonical_from_words(o0, o1);
   b = canonical_from_words(o2, o3);
+#endif
 }
 // unit-ball candidate (32 bits per coordinate); the spare word is the dielectric coin of
 // the bounce when this is its first candidate
-__device__ __forceinline__ V3 rng_scatter(Rng &g, uint32_t k0, uint32_t k1, double &coin) {
+__device__ __forceinline__ V3 rng_scatter(Rng &g, uint32_t k0, uint32_t k1, real &coin) {
   uint32_t o0, o1, o2, o3;
   philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
-  const double s32 = 0x1p-32;
-  coin = (double)o3 * s32;
-  return V3{(double)o0 * s32, (double)o1 * s32, (double)o2 * s32};
+  const real s32 = real(0x1p-32);
+  coin = (real)o3 * s32;
+  return V3{(real)o0 * s32, (real)o1 * s32, (real)o2 * s32};
 }
 
 // -------------------------------------------------------- primitive hit tests ---
 struct Closest {
-  double t;  // closest accepted root so far (the shrinking tmax of src/render.cpp:57-65)
+  real t;    // closest accepted root so far (the shrinking tmax of src/render.cpp:57-65)
   int prim;  // class-major primitive id, -1 = miss
 };
 
@@ -193,63 +246,66 @@ struct Closest {
 // the hit point and normal are computed once, for the winner only.
 // `inv_a` is 1/a, used only by the fast build (one reciprocal per ray instead of two
 // divisions per candidate hit); the strict build divides like the reference.
-__device__ __forceinline__ double sphere_disc(V3 o, V3 d, double a, double cx, double cy, double cz,
-                                              double r2, double &h) {
-  V3 oc = {o.x - cx, o.y - cy, o.z - cz};
+// T is the arithmetic of the test: `real`, or double for large primitives in the f32 build.
+__device__ __forceinline__ double rabs(double x) { return fabs(x); }
+__device__ __forceinline__ float rabs(float x) { return fabsf(x); }
+
+template <class T>
+__device__ __forceinline__ T sphere_disc(Vec3<T> o, Vec3<T> d, T a, T cx, T cy, T cz, T r2, T &h) {
+  Vec3<T> oc = {o.x - cx, o.y - cy, o.z - cz};
   h = dot(oc, d);
-  double c = dot(oc, oc) - fabs(r2);  // r2 carries the radius' sign (see rtow_capi.cpp)
+  T c = dot(oc, oc) - rabs(r2);  // r2 carries the radius' sign (see rtow_capi.cpp)
   return h * h - a * c;
 }
 
-__device__ __forceinline__ void sphere_resolve(double disc, double h, double a, double inv_a, int id,
-                                               double tmin, Closest &best);
-
-__device__ __forceinline__ void sphere_test(V3 o, V3 d, double a, double inv_a, double cx, double cy,
-                                            double cz, double r2, int id, double tmin, Closest &best) {
-  double h;
-  const double disc = sphere_disc(o, d, a, cx, cy, cz, r2, h);
-  sphere_resolve(disc, h, a, inv_a, id, tmin, best);
-}
-
-__device__ __forceinline__ void sphere_resolve(double disc, double h, double a, double inv_a, int id,
-                                               double tmin, Closest &best) {
-  if (disc >= 0.0) {
-    double sq = fast_sqrt(disc);
-#ifdef RTOW_FAST_MATH
-    double root = (-h - sq) * inv_a;
-    const double root2 = (-h + sq) * inv_a;
+template <class T>
+__device__ __forceinline__ void sphere_resolve(T disc, T h, T a, T inv_a, int id, T tmin, Closest &best) {
+  if (disc >= T(0.0)) {
+    T sq = fast_sqrt(disc);
+#if defined(RTOW_FAST_MATH)
+    T root = (-h - sq) * inv_a;
+    const T root2 = (-h + sq) * inv_a;
 #else
     (void)inv_a;
-    double root = (-h - sq) / a;
+    T root = (-h - sq) / a;
 #endif
     bool ok = true;
-    if (root < tmin || root > best.t) {
-#ifdef RTOW_FAST_MATH
+    if (root < tmin || root > (T)best.t) {
+#if defined(RTOW_FAST_MATH)
       root = root2;
 #else
       root = (-h + sq) / a;
 #endif
-      if (root < tmin || root > best.t) ok = false;
+      if (root < tmin || root > (T)best.t) ok = false;
     }
     if (ok) {
-      best.t = root;
+      best.t = (real)root;
       best.prim = id;
     }
   }
 }
 
+template <class T>
+__device__ __forceinline__ void sphere_test(Vec3<T> o, Vec3<T> d, T a, T inv_a, T cx, T cy, T cz, T r2, int id,
+                                            T tmin, Closest &best) {
+  T h;
+  const T disc = sphere_disc(o, d, a, cx, cy, cz, r2, h);
+  sphere_resolve(disc, h, a, inv_a, id, tmin, best);
+}
+
 // Triangle::hit (src/common-model.cpp:103-125) with e1, e2, n precomputed
-__device__ __forceinline__ void triangle_test(V3 o, V3 d, V3 A, V3 e1, V3 e2, V3 n, int id,
-                                              double tmin, Closest &best) {
-  double det = -dot(d, n);
-  double invdet = fast_rcp(det);  // strict build: 1.0 / det
-  V3 ao = o - A;
-  V3 dao = cross(ao, d);
-  double u = dot(e2, dao) * invdet;
-  double v = -dot(e1, dao) * invdet;
-  double t = dot(ao, n) * invdet;
-  if (det >= 1e-6 && t >= tmin && t <= best.t && u >= 0.0 && v >= 0.0 && (u + v) <= 1.0) {
-    best.t = t;
+template <class T>
+__device__ __forceinline__ void triangle_test(Vec3<T> o, Vec3<T> d, Vec3<T> A, Vec3<T> e1, Vec3<T> e2, Vec3<T> n,
+                                              int id, T tmin, Closest &best) {
+  T det = -dot(d, n);
+  T invdet = fast_rcp(det);  // strict build: 1.0 / det
+  Vec3<T> ao = o - A;
+  Vec3<T> dao = cross(ao, d);
+  T u = dot(e2, dao) * invdet;
+  T v = -dot(e1, dao) * invdet;
+  T t = dot(ao, n) * invdet;
+  if (det >= T(1e-6) && t >= tmin && t <= (T)best.t && u >= T(0.0) && v >= T(0.0) && (u + v) <= T(1.0)) {
+    best.t = (real)t;
     best.prim = id;
   }
 }
@@ -257,9 +313,11 @@ __device__ __forceinline__ void triangle_test(V3 o, V3 d, V3 A, V3 e1, V3 e2, V3
 #define RTOW_TMIN 0.001  // src/render.cpp:33
 
 // ------------------------------------------------------- closest hit: STREAM ---
-__device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, V3 d, double time) {
+// Always binary64 (in the f32 build the ray is widened once per segment): this kernel is for
+// scenes of <= 16 primitives, which include the r = 1000 ground sphere.
+__device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3d o, V3d d, double time) {
   Closest best;
-  best.t = __builtin_huge_val();  // tmax = +inf, src/render.cpp:34
+  best.t = (real)__builtin_huge_val();  // tmax = +inf, src/render.cpp:34
   best.prim = -1;
   const double tmin = RTOW_TMIN;
   const double a = dot(d, d);
@@ -269,7 +327,7 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, 
     const int n = sc.n_sph;
 #pragma unroll 4
     for (int i = 0; i < n; ++i) {
-      sphere_test(o, d, a, inv_a, g[4 * i + 0], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], i, tmin, best);
+      sphere_test<double>(o, d, a, inv_a, g[4 * i + 0], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], i, tmin, best);
     }
   }
   {
@@ -282,7 +340,7 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, 
       double cx = g[8 * i + 0] + time * g[8 * i + 3];
       double cy = g[8 * i + 1] + time * g[8 * i + 4];
       double cz = g[8 * i + 2] + time * g[8 * i + 5];
-      sphere_test(o, d, a, inv_a, cx, cy, cz, g[8 * i + 6], base + i, tmin, best);
+      sphere_test<double>(o, d, a, inv_a, cx, cy, cz, g[8 * i + 6], base + i, tmin, best);
     }
   }
   {
@@ -291,11 +349,11 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3 o, 
     const int base = sc.n_sph + sc.n_mov;
 #pragma unroll 2
     for (int i = 0; i < n; ++i) {
-      V3 A = {g[12 * i + 0], g[12 * i + 1], g[12 * i + 2]};
-      V3 e1 = {g[12 * i + 3], g[12 * i + 4], g[12 * i + 5]};
-      V3 e2 = {g[12 * i + 6], g[12 * i + 7], g[12 * i + 8]};
-      V3 nn = {g[12 * i + 9], g[12 * i + 10], g[12 * i + 11]};
-      triangle_test(o, d, A, e1, e2, nn, base + i, tmin, best);
+      V3d A = {g[12 * i + 0], g[12 * i + 1], g[12 * i + 2]};
+      V3d e1 = {g[12 * i + 3], g[12 * i + 4], g[12 * i + 5]};
+      V3d e2 = {g[12 * i + 6], g[12 * i + 7], g[12 * i + 8]};
+      V3d nn = {g[12 * i + 9], g[12 * i + 10], g[12 * i + 11]};
+      triangle_test<double>(o, d, A, e1, e2, nn, base + i, tmin, best);
     }
   }
   return best;
@@ -357,6 +415,9 @@ struct Image {
   }
 };
 
+__device__ __forceinline__ float round_up_f32(double t) { return __double2float_ru(t); }
+__device__ __forceinline__ float round_up_f32(float t) { return t; }
+
 __device__ __forceinline__ float safe_inv(float d) {
   // axis-parallel rays: a huge finite reciprocal keeps the fma slab form free of NaNs
   const float big = 1e30f;
@@ -365,15 +426,46 @@ __device__ __forceinline__ float safe_inv(float d) {
 
 struct ImgOffsets {  // byte offsets of the id and record sections inside a scene image
   uint32_t ids, sph, mov, tri;
+  uint32_t sph32, mov32;  // f32 build: binary32 copies of the sphere records (grid cells); `tri` then
+                          // points at binary32 triangle records (48 B), the only triangle section
 };
 
-// Tests primitives ids[first .. first+count) of a scene image against the ray (f64, the same
-// code as the STREAM kernel, so the accepted (t, primitive) is the same).
-template <bool LDS>
+// The ray of one segment in the forms the tests need.  In the binary64 builds the two forms
+// are the same values; in the f32 build the ray is widened once per segment for the tests
+// that must run in binary64.
+struct RayForms {
+  V3 o, d;
+  real a, inv_a, time;
+  V3d o64, d64;
+  double a64, inv_a64, time64;
+};
+__device__ __forceinline__ RayForms make_ray_forms(V3 o, V3 d, real time) {
+  RayForms r;
+  r.o = o;
+  r.d = d;
+  r.time = time;
+  r.a = dot(d, d);
+  r.inv_a = fast_rcp(r.a);  // used by the fast builds only
+  r.o64 = to_f64(o);
+  r.d64 = to_f64(d);
+  r.time64 = (double)time;
+#ifdef RTOW_REAL_F32
+  r.a64 = dot(r.d64, r.d64);
+  r.inv_a64 = fast_rcp(r.a64);
+#else
+  r.a64 = r.a;
+  r.inv_a64 = r.inv_a;
+#endif
+  return r;
+}
+
+// Tests primitives ids[first .. first+count) of a scene image against the ray (the same code
+// as the STREAM kernel, so the accepted (t, primitive) is the same).  SMALL: the spheres are
+// grid-cell members, tested in binary32 by the f32 build (no effect in the binary64 builds).
+template <bool LDS, bool SMALL>
 __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, ImgOffsets off,
-                                          uint32_t first, uint32_t count, V3 o, V3 d, double a,
-                                          double inv_a, double time, Closest &best, uint32_t &nprim,
-                                          int &last_id) {
+                                          uint32_t first, uint32_t count, const RayForms &ray, Closest &best,
+                                          uint32_t &nprim, int &last_id) {
   for (uint32_t k = 0; k < count; ++k) {
     const int id = (int)im.u32(off.ids + 4u * (first + k));
     // one-entry mailbox: a primitive spanning adjacent grid cells is listed in each of them
@@ -381,35 +473,57 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
     last_id = id;
     ++nprim;
     if (id < sc.n_sph) {
+#ifdef RTOW_REAL_F32
+      if constexpr (SMALL) {
+        const float4 p = im.f4(off.sph32 + 16u * (uint32_t)id);
+        sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p.x, p.y, p.z, p.w, id, (float)RTOW_TMIN, best);
+        continue;
+      }
+#endif
       const uint32_t r = off.sph + 32u * (uint32_t)id;
       const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
-      sphere_test(o, d, a, inv_a, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
     } else if (id < sc.n_sph + sc.n_mov) {
+#ifdef RTOW_REAL_F32
+      if constexpr (SMALL) {
+        const uint32_t r = off.mov32 + 32u * (uint32_t)(id - sc.n_sph);
+        const float4 p0 = im.f4(r), p1 = im.f4(r + 16u);  // c0xyz dx | dy dz r2 -
+        sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p0.x + ray.time * p0.w, p0.y + ray.time * p1.x,
+                           p0.z + ray.time * p1.y, p1.z, id, (float)RTOW_TMIN, best);
+        continue;
+      }
+#endif
       const uint32_t r = off.mov + 64u * (uint32_t)(id - sc.n_sph);
       const double2 p0 = im.d2(r), p1 = im.d2(r + 16u), p2 = im.d2(r + 32u), p3 = im.d2(r + 48u);
-      const double cx = p0.x + time * p1.y;
-      const double cy = p0.y + time * p2.x;
-      const double cz = p1.x + time * p2.y;
-      sphere_test(o, d, a, inv_a, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
+      const double cx = p0.x + ray.time64 * p1.y;
+      const double cy = p0.y + ray.time64 * p2.x;
+      const double cz = p1.x + ray.time64 * p2.y;
+      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
     } else {
+#ifdef RTOW_REAL_F32
+      const uint32_t r = off.tri + 48u * (uint32_t)(id - sc.n_sph - sc.n_mov);
+      const float4 q0 = im.f4(r), q1 = im.f4(r + 16u), q2 = im.f4(r + 32u);  // A e1 | e1 e2 | e2 n
+      triangle_test<float>(ray.o, ray.d, V3{q0.x, q0.y, q0.z}, V3{q0.w, q1.x, q1.y}, V3{q1.z, q1.w, q2.x},
+                           V3{q2.y, q2.z, q2.w}, id, (float)RTOW_TMIN, best);
+#else
       const uint32_t r = off.tri + 96u * (uint32_t)(id - sc.n_sph - sc.n_mov);
       const double2 q0 = im.d2(r), q1 = im.d2(r + 16u), q2 = im.d2(r + 32u), q3 = im.d2(r + 48u),
                     q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
-      triangle_test(o, d, V3{q0.x, q0.y, q1.x}, V3{q1.y, q2.x, q2.y}, V3{q3.x, q3.y, q4.x},
-                    V3{q4.y, q5.x, q5.y}, id, RTOW_TMIN, best);
+      triangle_test<double>(ray.o64, ray.d64, V3d{q0.x, q0.y, q1.x}, V3d{q1.y, q2.x, q2.y}, V3d{q3.x, q3.y, q4.x},
+                            V3d{q4.y, q5.x, q5.y}, id, RTOW_TMIN, best);
+#endif
     }
   }
 }
 
 template <bool LDS, bool ST>
 __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const DevScene &sc, V3 o,
-                                                   V3 d, double time, bool active, uint32_t &nnode,
+                                                   V3 d, real time, bool active, uint32_t &nnode,
                                                    uint32_t &nprim, Stamps<ST> &stamps) {
   Closest best;
-  best.t = __builtin_huge_val();
+  best.t = (real)__builtin_huge_val();
   best.prim = -1;
-  const double a = dot(d, d);
-  const double inv_a = fast_rcp(a);  // used by the fast build only
+  const RayForms ray = make_ray_forms(o, d, time);
   // f32 copy of the ray for the (conservative) box tests
   const float ix = safe_inv((float)d.x), iy = safe_inv((float)d.y), iz = safe_inv((float)d.z);
   const float oix = (float)o.x * ix, oiy = (float)o.y * iy, oiz = (float)o.z * iz;
@@ -417,7 +531,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   const float slack = 1.00002f;   // relative slack on the far side of the interval
   float tmax32 = __builtin_huge_valf();
   const uint32_t END = (uint32_t)sc.n_nodes;  // skip links past the last node point here
-  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri};
+  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri, sc.off_sph32, sc.off_mov32};
   int last_id = -1;
   uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
   uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u;  // queued leaves (0 = empty), oldest first
@@ -454,13 +568,13 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
       if constexpr (ST) stamps.phases += 1;
       // leaf phase: every lane tests the primitives of the OLDEST leaf it queued (most
       // lanes hold one; only the lanes whose queue filled hold two, and theirs moves up)
-      if (q0 != 0u) leaf_test(im, sc, off, q0 >> 3, q0 & 7u, o, d, a, inv_a, time, best, nprim, last_id);
+      if (q0 != 0u) leaf_test<LDS, false>(im, sc, off, q0 >> 3, q0 & 7u, ray, best, nprim, last_id);
       q0 = q1;
       q1 = q2;
       q2 = q3;
       q3 = 0u;
       // shrink the f32 interval (rounded up: never below the f64 value)
-      tmax32 = __double2float_ru(best.t);
+      tmax32 = round_up_f32(best.t);
       stamps.mark(RG_LEAF);
       if (!any_walking && !__any(q0 != 0u)) break;
     }
@@ -477,14 +591,13 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
 // the current cell is beyond the closest hit so far.
 template <bool LDS, bool ST>
 __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const DevScene &sc, V3 o,
-                                                    V3 d, double time, bool active, uint32_t &nnode,
+                                                    V3 d, real time, bool active, uint32_t &nnode,
                                                     uint32_t &nprim, Stamps<ST> &stamps) {
   Closest best;
-  best.t = __builtin_huge_val();
+  best.t = (real)__builtin_huge_val();
   best.prim = -1;
-  const double a = dot(d, d);
-  const double inv_a = fast_rcp(a);  // used by the fast build only
-  const ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri};
+  const RayForms ray = make_ray_forms(o, d, time);
+  const ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri, sc.g_off_sph32, sc.g_off_mov32};
   int last_id = -1;
   // header: wave-uniform scalar loads from the global copy of the image
   const RTOW_CONST float *hf = (const RTOW_CONST float *)sc.gblob;
@@ -511,14 +624,14 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         for (int j = 0; j < 4; ++j) {
           const uint32_t r = off.sph + 32u * (uint32_t)id[j];
           const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
-          dd[j] = sphere_disc(o, d, a, p0.x, p0.y, p1.x, p1.y, hh[j]);
+          dd[j] = sphere_disc<double>(ray.o64, ray.d64, ray.a64, p0.x, p0.y, p1.x, p1.y, hh[j]);
         }
         nprim += 4u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sphere_resolve(dd[j], hh[j], a, inv_a, id[j], RTOW_TMIN, best);
+        for (int j = 0; j < 4; ++j) sphere_resolve<double>(dd[j], hh[j], ray.a64, ray.inv_a64, id[j], RTOW_TMIN, best);
         last_id = id[3];
       } else {
-        leaf_test(im, sc, off, lf + k, 4u, o, d, a, inv_a, time, best, nprim, last_id);
+        leaf_test<LDS, false>(im, sc, off, lf + k, 4u, ray, best, nprim, last_id);
       }
     }
     for (; k + 1 < n_large; k += 2) {
@@ -527,19 +640,19 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         const uint32_t ra = off.sph + 32u * (uint32_t)ia, rb = off.sph + 32u * (uint32_t)ib;
         const double2 a0 = im.d2(ra), a1 = im.d2(ra + 16u), b0 = im.d2(rb), b1 = im.d2(rb + 16u);
         double ha, hb;
-        const double da = sphere_disc(o, d, a, a0.x, a0.y, a1.x, a1.y, ha);
-        const double db = sphere_disc(o, d, a, b0.x, b0.y, b1.x, b1.y, hb);
+        const double da = sphere_disc<double>(ray.o64, ray.d64, ray.a64, a0.x, a0.y, a1.x, a1.y, ha);
+        const double db = sphere_disc<double>(ray.o64, ray.d64, ray.a64, b0.x, b0.y, b1.x, b1.y, hb);
         nprim += 2u;
-        sphere_resolve(da, ha, a, inv_a, ia, RTOW_TMIN, best);
-        sphere_resolve(db, hb, a, inv_a, ib, RTOW_TMIN, best);
+        sphere_resolve<double>(da, ha, ray.a64, ray.inv_a64, ia, RTOW_TMIN, best);
+        sphere_resolve<double>(db, hb, ray.a64, ray.inv_a64, ib, RTOW_TMIN, best);
         last_id = ib;
       } else {
-        leaf_test(im, sc, off, lf + k, 2u, o, d, a, inv_a, time, best, nprim, last_id);
+        leaf_test<LDS, false>(im, sc, off, lf + k, 2u, ray, best, nprim, last_id);
       }
     }
-    if (k < n_large) leaf_test(im, sc, off, lf + k, n_large - k, o, d, a, inv_a, time, best, nprim, last_id);
+    if (k < n_large) leaf_test<LDS, false>(im, sc, off, lf + k, n_large - k, ray, best, nprim, last_id);
   }
-  float tmax32 = __double2float_ru(best.t);
+  float tmax32 = round_up_f32(best.t);
 
   // clip the ray to the grid bounds (f32, conservative by the padding of rtow_grid.h)
   const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
@@ -599,10 +712,10 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
     if (__any(q1 != 0u) || !any_walking) {
       stamps.mark(RG_WALK);
       if constexpr (ST) stamps.phases += 1;
-      if (q0 != 0u) leaf_test(im, sc, off, q0 >> 8, q0 & 255u, o, d, a, inv_a, time, best, nprim, last_id);
+      if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
       q0 = q1;
       q1 = 0u;
-      tmax32 = __double2float_ru(best.t);
+      tmax32 = round_up_f32(best.t);
       stamps.mark(RG_LEAF);
       if (!any_walking && !__any(q0 != 0u)) break;
     }
@@ -665,9 +778,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   uint32_t item = 0xffffffffu;
   uint32_t j = 0;             // column
   uint32_t gi = 0;            // global row (from the top)
-  V3 acc = {0.0, 0.0, 0.0};   // pixel_color of this item (src/render.cpp:156)
+  V3d acc = {0.0, 0.0, 0.0};  // pixel_color of this item (src/render.cpp:156), binary64 in every build
   V3 ro = {0, 0, 0}, rd = {0, 0, 1};
-  double rtime = 0.0;
+  real rtime = 0;
   int depth = 0;              // remaining child rays
   int nb = 0;                 // bounces recorded on the path stack
   Rng g = {0, 0, 0};
@@ -791,7 +904,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         // only the ready lanes active, and an inactive source lane reads as 0)
         const uint32_t partner_holds = lane_read(src, (uint32_t)holding);
         const bool take = ready && partner_holds != 0u;
-        const V3 c = {lane_read(src, acc.x), lane_read(src, acc.y), lane_read(src, acc.z)};
+        const V3d c = {lane_read(src, acc.x), lane_read(src, acc.y), lane_read(src, acc.z)};
         // a holding helper asks its owner whether it was the one taken
         const uint32_t ow = holding ? partners : lane;
         const bool o_take = lane_read(ow, (uint32_t)take) != 0u;
@@ -862,24 +975,28 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       g.r = 0u;
       // src/render.cpp:158-159
       const int from_top_i = P.H - (int)gi - 1;
-      double ju, jv, jt;
+      real ju, jv, jt;
       rng_jitter(g, k0, k1, ju, jv, jt);
-      const double u = fast_div((double)(int)j + ju, (double)(P.W - 1));
-      const double v = fast_div((double)from_top_i + jv, (double)(P.H - 1));
+      const real u = fast_div((real)(int)j + ju, (real)(P.W - 1));
+      const real v = fast_div((real)from_top_i + jv, (real)(P.H - 1));
       // src/common-model.cpp:156-167; disk sample: y draws first (random-utils.cpp:36)
-      double px, py;
+      real px, py;
       for (;;) {
-        double c0, c1;
+        real c0, c1;
         rng_disk(g, k0, k1, c0, c1);
-        py = c0 * (1.0 - -1.0) + -1.0;
-        px = c1 * (1.0 - -1.0) + -1.0;
-        if (px * px + py * py + 0.0 * 0.0 >= 1.0) continue;
+        py = c0 * (real(1.0) - real(-1.0)) + real(-1.0);
+        px = c1 * (real(1.0) - real(-1.0)) + real(-1.0);
+        if (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) continue;
         break;
       }
       // camera block: wave-uniform scalar loads (origin u v horizontal vertical llc | lens t0 t1)
+#ifdef RTOW_REAL_F32
+      const RTOW_CONST float *cm = (const RTOW_CONST float *)P.cam32;
+#else
       cdptr cm = (cdptr)(const double *)P.cam;
-      const double lens = cm[18], ct0 = cm[19], ct1 = cm[20];
-      const double rdx = lens * px, rdy = lens * py;
+#endif
+      const real lens = cm[18], ct0 = cm[19], ct1 = cm[20];
+      const real rdx = lens * px, rdy = lens * py;
       const V3 offset = V3{cm[3], cm[4], cm[5]} * rdx + V3{cm[6], cm[7], cm[8]} * rdy;
       const V3 from = V3{cm[0], cm[1], cm[2]} + offset;
       rd = V3{cm[15], cm[16], cm[17]} + u * V3{cm[9], cm[10], cm[11]} + v * V3{cm[12], cm[13], cm[14]} - from;
@@ -894,7 +1011,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     if constexpr (STAMPS) stamps.trips += 1;
     // ---- one ray segment: closest hit --------------------------------------------
     Closest best;
-    best.t = 0.0;
+    best.t = 0;
     best.prim = -1;
     if constexpr (KERNEL == 3) {
       best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
@@ -902,7 +1019,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       // the walk uses wave votes, so every lane of the wave enters it
       best = closest_hit_bvh<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
     } else {
-      if (live) best = closest_hit_stream(sc, ro, rd, rtime);
+      if (live) best = closest_hit_stream(sc, to_f64(ro), to_f64(rd), (double)rtime);
     }
 
     stamps.mark(RG_WALK);
@@ -920,7 +1037,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
           bool front = true;
           const int pid = best.prim;
           int mi, kind;
-          double m_fuzz, m_ir;
+          real m_fuzz, m_ir;
           if constexpr (KERNEL >= 2) {
             const uint32_t o_sph = KERNEL == 3 ? sc.g_off_sph : sc.off_sph;
             const uint32_t o_mov = KERNEL == 3 ? sc.g_off_mov : sc.off_mov;
@@ -929,76 +1046,90 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             const uint32_t o_mats = KERNEL == 3 ? sc.g_off_mats : sc.off_mats;
             if (pid < sc.n_sph + sc.n_mov) {
               V3 center;
-              double radius;
+              bool inward;  // negative radius: only the sign of the signed r*r is used here
               if (pid < sc.n_sph) {
                 const double2 p0 = im.d2(o_sph + 32u * (uint32_t)pid), p1 = im.d2(o_sph + 32u * (uint32_t)pid + 16u);
-                center = {p0.x, p0.y, p1.x};
-                radius = p1.y;  // signed r*r: only the sign is used below
+                center = {(real)p0.x, (real)p0.y, (real)p1.x};
+                inward = p1.y < 0.0;
               } else {
                 const uint32_t r = o_mov + 64u * (uint32_t)(pid - sc.n_sph);
                 const double2 p0 = im.d2(r), p1 = im.d2(r + 16u), p2 = im.d2(r + 32u), p3 = im.d2(r + 48u);
+#ifdef RTOW_REAL_F32
+                center = {(real)p0.x + rtime * (real)p1.y, (real)p0.y + rtime * (real)p2.x, (real)p1.x + rtime * (real)p2.y};
+#else
                 center = {p0.x + rtime * p1.y, p0.y + rtime * p2.x, p1.x + rtime * p2.y};
-                radius = p3.x;  // signed r*r
+#endif
+                inward = p3.x < 0.0;
               }
               normal = normalize(where - center);
-              front = (dot(rd, normal) < 0.0) ^ (radius < 0.0);
+              front = (dot(rd, normal) < real(0.0)) ^ inward;
               normal = front ? normal : -normal;
             } else {
+#ifdef RTOW_REAL_F32
+              const uint32_t r = o_tri + 48u * (uint32_t)(pid - sc.n_sph - sc.n_mov);
+              const float4 q2 = im.f4(r + 32u);
+              normal = {q2.y, q2.z, q2.w};
+#else
               const uint32_t r = o_tri + 96u * (uint32_t)(pid - sc.n_sph - sc.n_mov);
               const double2 q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
               normal = {q4.y, q5.x, q5.y};
+#endif
             }
             mi = (int)im.u32(o_pmat + 4u * (uint32_t)pid);
             const uint32_t mr = o_mats + 48u * (uint32_t)mi;
             const double2 m1 = im.d2(mr + 16u), m2 = im.d2(mr + 32u);  // {att.z, fuzz}, {ir, kind|pad}
-            m_fuzz = m1.y;
-            m_ir = m2.x;
+            m_fuzz = (real)m1.y;
+            m_ir = (real)m2.x;
             kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
           } else {
             if (pid < sc.n_sph + sc.n_mov) {
               V3 center;
-              double radius;
+              bool inward;
               if (pid < sc.n_sph) {
                 const double *q = sc.sph + 4 * (size_t)pid;
-                center = {q[0], q[1], q[2]};
-                radius = sc.sph_r[pid];
+                center = {(real)q[0], (real)q[1], (real)q[2]};
+                inward = sc.sph_r[pid] < 0.0;
               } else {
                 const double *q = sc.mov + 8 * (size_t)(pid - sc.n_sph);
+#ifdef RTOW_REAL_F32
+                center = {(real)q[0] + rtime * (real)q[3], (real)q[1] + rtime * (real)q[4], (real)q[2] + rtime * (real)q[5]};
+#else
                 center = {q[0] + rtime * q[3], q[1] + rtime * q[4], q[2] + rtime * q[5]};
-                radius = q[7];
+#endif
+                inward = q[7] < 0.0;
               }
               normal = normalize(where - center);
-              front = (dot(rd, normal) < 0.0) ^ (radius < 0.0);
+              front = (dot(rd, normal) < real(0.0)) ^ inward;
               normal = front ? normal : -normal;
             } else {
               const double *q = sc.tri + 12 * (size_t)(pid - sc.n_sph - sc.n_mov);
-              normal = {q[9], q[10], q[11]};
+              normal = {(real)q[9], (real)q[10], (real)q[11]};
             }
             mi = sc.prim_mat[pid];
             const DevMaterial *m = sc.mats + mi;
             kind = m->kind;
-            m_fuzz = m->fuzz;
-            m_ir = m->ir;
+            m_fuzz = (real)m->fuzz;
+            m_ir = (real)m->ir;
           }
 
           // ---- Material::scatter (src/common-model.cpp:13-62) ------------------
           // first unit-ball candidate of this bounce; its block also carries the coin
-          double coin;
+          real coin;
           V3 rnd = rng_scatter(g, k0, k1, coin);
-          V3 dirbase = {0.0, 0.0, 0.0};
+          V3 dirbase = {0, 0, 0};
           if (kind == 2) {
-            const double ir = m_ir;
+            const real ir = m_ir;
             const V3 unit = normalize(rd);
-            const double cos_theta = dot(-unit, normal);
-            const double sin_theta = fast_sqrt(1.0 - cos_theta * cos_theta);
-            const double ratio = front ? fast_rcp(ir) : ir;
-            bool refl = ratio * sin_theta > 1.0;
+            const real cos_theta = dot(-unit, normal);
+            const real sin_theta = fast_sqrt(real(1.0) - cos_theta * cos_theta);
+            const real ratio = front ? fast_rcp(ir) : ir;
+            bool refl = ratio * sin_theta > real(1.0);
             if (!refl) {
-              double r0 = fast_div(1.0 - ratio, 1.0 + ratio);
+              real r0 = fast_div(real(1.0) - ratio, real(1.0) + ratio);
               r0 = r0 * r0;
-              const double x = 1.0 - cos_theta;
-              const double x2 = x * x;
-              const double R = r0 + (1.0 - r0) * (x2 * x2 * x);
+              const real x = real(1.0) - cos_theta;
+              const real x2 = x * x;
+              const real R = r0 + (real(1.0) - r0) * (x2 * x2 * x);
               refl = R > coin;
             }
             dirbase = refl ? reflect(unit, normal) : refract(unit, normal, ratio);
@@ -1006,15 +1137,15 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             dirbase = reflect(rd, normal);
           }
           // random_unit_vector(): reject candidates outside the unit ball (random-utils.cpp:23-33)
-          while (dot(rnd, rnd) >= 1.0) {
-            double unused;
+          while (dot(rnd, rnd) >= real(1.0)) {
+            real unused;
             rnd = rng_scatter(g, k0, k1, unused);
           }
           V3 dir;
           bool absorbed = false;
           if (kind == 0) {
-            absorbed = fabs(normal.x - rnd.x) < 1e-8 && fabs(normal.y - rnd.y) < 1e-8 &&
-                       fabs(normal.z - rnd.z) < 1e-8;
+            absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
+                       rabs(normal.z - rnd.z) < real(1e-8);
             dir = normal + rnd;
           } else {
             dir = dirbase + m_fuzz * rnd;
@@ -1032,20 +1163,20 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       } else {
         // ---- background + unwind of the recursion (src/render.cpp:119,122-128) --
         const V3 unit = normalize(rd);
-        const double t = 0.5 * (unit.y + +1.0);
-        V3 c = (1.0 - t) * V3{1.0, 1.0, 1.0} + t * V3{0.5, 0.7, 1.0};
+        const real t = real(0.5) * (unit.y + real(+1.0));
+        V3 c = (real(1.0) - t) * V3{1, 1, 1} + t * V3{real(0.5), real(0.7), real(1.0)};
         for (int q = nb - 1; q >= 0; --q) {
           const uint32_t smi = P.stack[(size_t)q * P.n_lanes + lane_g];
           if constexpr (KERNEL >= 2) {
             const uint32_t mr = (KERNEL == 3 ? sc.g_off_mats : sc.off_mats) + 48u * smi;
             const double2 a0 = im.d2(mr), a1 = im.d2(mr + 16u);
-            c = V3{a0.x, a0.y, a1.x} * c;
+            c = V3{(real)a0.x, (real)a0.y, (real)a1.x} * c;
           } else {
             const DevMaterial *m = sc.mats + smi;
-            c = V3{m->att[0], m->att[1], m->att[2]} * c;
+            c = V3{(real)m->att[0], (real)m->att[1], (real)m->att[2]} * c;
           }
         }
-        acc = acc + c;  // pixel_color += ray_color(...)
+        acc = acc + to_f64(c);  // pixel_color += ray_color(...)
         need_sample = true;
       }
       if (need_sample) {
