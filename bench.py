@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
     ap.add_argument("--no-scaling-base", action="store_true",
                     help="N=1: skip the extra configs[2] (500 spp) measurement on this GPU")
-    ap.add_argument("--precision", choices=["fast", "strict"], default="fast")
+    ap.add_argument("--precision", choices=["fast", "strict", "f32"], default="fast",
+                    help="fast/strict: binary64 (the metric's arithmetic); f32: the preview build, never the headline")
     ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid"], default="auto")
     ap.add_argument("--moving", action="store_true", help="moving-sphere variant of the cover scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,7 +143,7 @@ def main():
     spp = a.spp or (100 if world == 1 else 500)
     nstreams = max(1, spp // SAMPLES_PER_ITEM)
     tile_rows = 4 if H % (4 * world) == 0 else 8
-    precision = rtow.F64_FAST if a.precision == "fast" else rtow.F64_STRICT
+    precision = {"fast": rtow.F64_FAST, "strict": rtow.F64_STRICT, "f32": rtow.F32}[a.precision]
     kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID}[a.kernel]
     split_samples = a.split == "samples" and world > 1
     if split_samples:
@@ -252,7 +253,8 @@ def main():
             "metric": "Msamples/sec (W×H×spp) on cover scene; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if a.precision != "f32" else "f32 (preview build: NOT the metric's binary64 arithmetic)",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "config": {
                 "workload": f"RTOW cover scene ({n_prims} prims, {'moving' if a.moving else 'static'}) "

@@ -53,6 +53,11 @@ extern "C" {
 /* arithmetic modes of the device path */
 #define RTOW_F64_STRICT 0 /* binary64, no FMA contraction: bit-identical to the CPU oracle */
 #define RTOW_F64_FAST 1   /* binary64, FMA contraction allowed (default for speed)         */
+#define RTOW_F32 2        /* binary32 rays, small-primitive tests and shading on binary32
+                             records; large primitives and pixel sums stay binary64.
+                             NOT the reference's arithmetic: a faster preview mode whose
+                             parity with the binary64 builds is by tolerance (<= 1/255 mean
+                             absolute difference per channel at >= 100 spp)             */
 
 /* closest-hit strategies */
 #define RTOW_KERNEL_AUTO 0

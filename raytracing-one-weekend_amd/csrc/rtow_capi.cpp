@@ -105,6 +105,44 @@ int upload(DevBuf &b, const std::vector<T> &v) {
   return RTOW_OK;
 }
 
+// Scene image of the f32 build, derived from a binary64 image: the same prefix (nodes or
+// header+cells, then ids — everything before the sphere records), the binary64 sphere and moving
+// records (large-primitive list, BVH kernel, shading), binary32 triangle records (the only
+// triangle section), binary32 sphere and moving records (grid cells), material indices, materials.
+struct Image32 {
+  std::vector<unsigned char> blob;  // prefix left zeroed when `prefix` is NULL (filled on the device)
+  uint32_t off_sph = 0, off_mov = 0, off_tri = 0, off_sph32 = 0, off_mov32 = 0, off_pmat = 0, off_mats = 0;
+};
+void make_image32(const unsigned char *prefix, uint32_t prefix_bytes, const std::vector<double> &sph,
+                  const std::vector<double> &mov, const std::vector<double> &tri, const std::vector<int32_t> &pmat,
+                  const std::vector<unsigned char> &mats_bytes, Image32 &out) {
+  auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
+  const size_t ns = sph.size() / 4, nm = mov.size() / 8, nt = tri.size() / 12;
+  out.off_sph = prefix_bytes;
+  out.off_mov = (uint32_t)(out.off_sph + ns * 32);
+  out.off_tri = (uint32_t)(out.off_mov + nm * 64);
+  out.off_sph32 = (uint32_t)up16(out.off_tri + nt * 48);
+  out.off_mov32 = (uint32_t)(out.off_sph32 + ns * 16);
+  out.off_pmat = (uint32_t)up16(out.off_mov32 + nm * 32);
+  out.off_mats = (uint32_t)up16(out.off_pmat + pmat.size() * 4);
+  out.blob.assign(up16(out.off_mats + mats_bytes.size()), 0);
+  unsigned char *b = out.blob.data();
+  if (prefix) std::memcpy(b, prefix, prefix_bytes);
+  if (ns) std::memcpy(b + out.off_sph, sph.data(), ns * 32);
+  if (nm) std::memcpy(b + out.off_mov, mov.data(), nm * 64);
+  float *t32 = reinterpret_cast<float *>(b + out.off_tri);
+  for (size_t i = 0; i < nt * 12; ++i) t32[i] = (float)tri[i];  // A e1 e2 n, 12 floats per triangle
+  float *s32 = reinterpret_cast<float *>(b + out.off_sph32);
+  for (size_t i = 0; i < ns * 4; ++i) s32[i] = (float)sph[i];    // cx cy cz copysign(r*r, r)
+  float *m32 = reinterpret_cast<float *>(b + out.off_mov32);
+  for (size_t i = 0; i < nm; ++i) {                              // c0xyz dx | dy dz copysign(r*r, r) 0
+    for (int k = 0; k < 7; ++k) m32[i * 8 + k] = (float)mov[i * 8 + k];
+    m32[i * 8 + 7] = 0.0f;
+  }
+  if (!pmat.empty()) std::memcpy(b + out.off_pmat, pmat.data(), pmat.size() * 4);
+  if (!mats_bytes.empty()) std::memcpy(b + out.off_mats, mats_bytes.data(), mats_bytes.size());
+}
+
 double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -129,6 +167,8 @@ struct rtow_ctx {
   int n_prims = 0;
   // scene buffers
   DevBuf sph, sph_r, mov, tri, prim_mat, mats, blob, cam_dev, gblob;
+  DevBuf blob32, gblob32, cam32_dev;  // the f32 build's scene images and camera
+  rtow::DevScene ds32{};               // ds with the f32 images' pointers and offsets
   uint32_t gblob_bytes = 0;
   bool have_grid = false;
   uint32_t blob_bytes = 0;
@@ -139,7 +179,7 @@ struct rtow_ctx {
   // workspace
   DevBuf partials, stack, counters;
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
-  int occ[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  int occ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
   hipEvent_t ev[kEventRing][2];
   bool ev_ready = false;
@@ -185,6 +225,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
+                    &c->blob32, &c->gblob32, &c->cam32_dev,
                     &c->partials, &c->stack, &c->counters})
     b->release();
   if (c->ev_ready) {
@@ -407,6 +448,46 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     std::vector<rtow::DevCamera> one(1, dc);
     if ((rc = upload(c->cam_dev, one))) return rc;
   }
+  // ---- the f32 build's images (same trees, binary32 records for the small primitives) ----
+  {
+    Image32 b32;
+    const bool device_tree = c->builder == RTOW_BUILDER_DEVICE_LBVH;
+    make_image32(device_tree ? nullptr : img.blob.data(), img.off_sph, sph, mov, tri, pmat, mats_bytes, b32);
+    if ((rc = upload(c->blob32, b32.blob))) return rc;
+    if (device_tree)  // nodes + ids exist only in HBM
+      HIPCHK(hipMemcpy(c->blob32.p, c->blob.p, img.off_sph, hipMemcpyDeviceToDevice));
+    rtow::DevScene &d32 = c->ds32;
+    d32 = c->ds;
+    d32.blob = (const unsigned char *)c->blob32.p;
+    d32.blob_bytes = (uint32_t)b32.blob.size();
+    d32.off_sph = b32.off_sph;
+    d32.off_mov = b32.off_mov;
+    d32.off_tri = b32.off_tri;
+    d32.off_sph32 = b32.off_sph32;
+    d32.off_mov32 = b32.off_mov32;
+    d32.off_pmat = b32.off_pmat;
+    d32.off_mats = b32.off_mats;
+    d32.gblob = nullptr;
+    d32.gblob_bytes = 0;
+    if (gimg.ok) {
+      Image32 g32;
+      make_image32(gimg.blob.data(), gimg.off_sph, sph, mov, tri, pmat, mats_bytes, g32);
+      if ((rc = upload(c->gblob32, g32.blob))) return rc;
+      d32.gblob = (const unsigned char *)c->gblob32.p;
+      d32.gblob_bytes = (uint32_t)g32.blob.size();
+      d32.g_off_sph = g32.off_sph;
+      d32.g_off_mov = g32.off_mov;
+      d32.g_off_tri = g32.off_tri;
+      d32.g_off_sph32 = g32.off_sph32;
+      d32.g_off_mov32 = g32.off_mov32;
+      d32.g_off_pmat = g32.off_pmat;
+      d32.g_off_mats = g32.off_mats;
+    }
+    const double *cd = reinterpret_cast<const double *>(&dc);
+    std::vector<float> cam32(21);
+    for (int i = 0; i < 21; ++i) cam32[i] = (float)cd[i];
+    if ((rc = upload(c->cam32_dev, cam32))) return rc;
+  }
   c->have_scene = true;
   rtow_build_info_t &bi = c->build_info;
   bi.builder = c->builder;
@@ -429,7 +510,7 @@ static int validate_cfg(const rtow_config_t *cfg) {
   if (cfg->nranks <= 0 || cfg->rank < 0 || cfg->rank >= cfg->nranks)
     return fail(RTOW_EINVAL, "rank %d of %d", cfg->rank, cfg->nranks);
   if (cfg->tile_rows <= 0) return fail(RTOW_EINVAL, "tile_rows must be >= 1");
-  if (cfg->precision != RTOW_F64_STRICT && cfg->precision != RTOW_F64_FAST)
+  if (cfg->precision != RTOW_F64_STRICT && cfg->precision != RTOW_F64_FAST && cfg->precision != RTOW_F32)
     return fail(RTOW_EINVAL, "unknown precision %d", cfg->precision);
   if (cfg->kernel < RTOW_KERNEL_AUTO || cfg->kernel > RTOW_KERNEL_GRID)
     return fail(RTOW_EINVAL, "unknown kernel %d", cfg->kernel);
@@ -507,6 +588,8 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
              : (c->have_grid && c->ds.n_tri == 0) ? RTOW_KERNEL_GRID : RTOW_KERNEL_BVH;
   if (kernel == RTOW_KERNEL_GRID && !c->have_grid) kernel = RTOW_KERNEL_BVH;  // scene not suited to a grid
   const bool strict = cfg->precision == RTOW_F64_STRICT;
+  const bool f32 = cfg->precision == RTOW_F32;
+  const rtow::DevScene &scene = f32 ? c->ds32 : c->ds;
   int block = kernel >= RTOW_KERNEL_BVH ? kBvhBlock : kBlock;
   if (kernel >= RTOW_KERNEL_BVH)
     if (const char *e = std::getenv("RTOW_BVH_BLOCK")) {  // experiment knob
@@ -514,7 +597,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
       if (b == 256 || b == 512 || b == 1024) block = b;
     }
   // the scene image goes to LDS when one copy per workgroup fits (160 KiB per CU)
-  const uint32_t image_bytes = kernel == RTOW_KERNEL_GRID ? c->gblob_bytes : c->blob_bytes;
+  const uint32_t image_bytes = kernel == RTOW_KERNEL_GRID ? scene.gblob_bytes : scene.blob_bytes;
   const unsigned lds_bytes = (kernel >= RTOW_KERNEL_BVH && image_bytes <= kLdsLimit) ? image_bytes : 0u;
 
   if (stats) {
@@ -531,9 +614,10 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   }
 
   // grid: as many 256-lane blocks as stay resident, but no more than there are items
-  int &occ = c->occ[strict ? 0 : 1][kernel - 1];
+  int &occ = c->occ[strict ? 0 : (f32 ? 2 : 1)][kernel - 1];
   if (occ <= 0) {
     occ = strict ? rtow::trace_occupancy_strict(kernel, block, lds_bytes)
+          : f32  ? rtow::trace_occupancy_f32(kernel, block, lds_bytes)
                  : rtow::trace_occupancy_fast(kernel, block, lds_bytes);
     if (occ <= 0) return fail(RTOW_EHIP, "occupancy query failed (kernel %d, %u B of LDS)", kernel, lds_bytes);
     if (occ > 8) occ = 8;
@@ -556,8 +640,9 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
 
   rtow::TraceParams P;
   std::memset(&P, 0, sizeof P);
-  P.sc = c->ds;
+  P.sc = scene;
   P.cam = (const rtow::DevCamera *)c->cam_dev.p;
+  P.cam32 = (const float *)c->cam32_dev.p;
   P.W = cfg->image_width;
   P.H = cfg->image_height;
   P.spt = spt;
@@ -605,6 +690,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   int launch_kernel = kernel;
   if (kernel >= RTOW_KERNEL_BVH && lds_bytes > 0 && std::getenv("RTOW_STAMPS")) launch_kernel = kernel + 16;  // diagnostic
   int lrc = strict ? rtow::launch_trace_strict(P, launch_kernel, (int)grid, block, lds_bytes, st)
+            : f32  ? rtow::launch_trace_f32(P, launch_kernel, (int)grid, block, lds_bytes, st)
                    : rtow::launch_trace_fast(P, launch_kernel, (int)grid, block, lds_bytes, st);
   if (lrc != 0) return fail(RTOW_EHIP, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   if (slot >= 0) {

@@ -198,13 +198,13 @@ __device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint
   v = ((double)o1 + (double)((o3 >> 10) & 1023u) * 4294967296.0) * s42;
   t = ((double)o2 + (double)((o3 >> 20) & 1023u) * 4294967296.0) * s42;
 }
-// binary32 build: the same blocks, 32 bits per value (a value that rounds up to 1.0 is harmless:
-// it moves a sample by one ulp of the pixel grid, and a rejection candidate at 1.0 is rejected)
-__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t, float &u,
+// binary32 build: the top 24 bits of the same 42-bit values (truncated, so < 1 and within one
+// binary32 ulp of the binary64 build's value: both builds sample the same lens/pixel positions)
+__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, float &u,
                                                   float &v, float &t) {
-  u = (float)o0 * 0x1p-32f;
-  v = (float)o1 * 0x1p-32f;
-  t = (float)o2 * 0x1p-32f;
+  u = (float)(((o3 & 1023u) << 14) | (o0 >> 18)) * 0x1p-24f;
+  v = (float)((((o3 >> 10) & 1023u) << 14) | (o1 >> 18)) * 0x1p-24f;
+  t = (float)((((o3 >> 20) & 1023u) << 14) | (o2 >> 18)) * 0x1p-24f;
 }
 __device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, real &u, real &v, real &t) {
   uint32_t o0, o1, o2, o3;

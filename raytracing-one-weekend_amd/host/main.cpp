@@ -29,7 +29,7 @@ static void usage(const char *argv0) {
                "  -l,--load TEXT              Model to load\n"
                "  --device INT                HIP device index (default 0)\n"
                "  --seed UINT                 render seed of the counter-based RNG (default 1)\n"
-               "  --precision strict|fast     f64 without / with FMA contraction (default fast)\n"
+               "  --precision strict|fast|f32 f64 without / with FMA contraction (default fast); f32 = binary32 preview\n"
                "  --kernel auto|brute|bvh|grid  closest-hit strategy (default auto)\n"
                "  --builder host|device       BVH build: host SAH (default) or on the GPU (LBVH)\n"
                "  --p6                        binary P6 output, write_color on the device\n";
@@ -81,7 +81,8 @@ int main(int argc, char *argv[]) {
         const std::string v = value();
         if (v == "strict") opt.precision = 0;
         else if (v == "fast") opt.precision = 1;
-        else throw std::runtime_error("--precision: strict|fast");
+        else if (v == "f32") opt.precision = 2;
+        else throw std::runtime_error("--precision: strict|fast|f32");
       } else if (std::strcmp(a, "--p6") == 0) {
         opt.binary_ppm = true;
       } else if (std::strcmp(a, "--builder") == 0) {

@@ -21,7 +21,7 @@ RTOW_ABI_VERSION = 3
 RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY = 0, -1, -2, -3, -4, -5
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
-F64_STRICT, F64_FAST = 0, 1
+F64_STRICT, F64_FAST, F32 = 0, 1, 2
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH, KERNEL_GRID = 0, 1, 2, 3
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1
 

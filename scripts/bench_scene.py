@@ -16,7 +16,7 @@ ap.add_argument("--width", type=int, default=0)
 ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--depth", type=int, default=0)
 ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--precision", default="fast")
+ap.add_argument("--precision", default="fast", choices=["fast", "strict", "f32"])
 ap.add_argument("--kernel", default="auto")
 ap.add_argument("--subdiv", type=int, default=10)
 ap.add_argument("--builder", default="host", choices=["host", "device"])
@@ -34,7 +34,7 @@ else:
 W = a.width or W; spp = a.spp or spp; depth = a.depth or depth
 H = rtow.image_height(W, aspect)
 cfg = rtow.make_config(W, H, spp, max(1, spp // 8 if a.scene in ("suzanne", "mesh100k") else spp // 10), depth, seed=1,
-                       precision=rtow.F64_FAST if a.precision == "fast" else rtow.F64_STRICT,
+                       precision={"fast": rtow.F64_FAST, "strict": rtow.F64_STRICT, "f32": rtow.F32}[a.precision],
                        kernel={"auto": 0, "brute": 1, "bvh": 2, "grid": 3}[a.kernel])
 ctx = rtow.Context(0)
 ctx.set_builder(rtow.BUILDER_DEVICE_LBVH if a.builder == "device" else rtow.BUILDER_HOST_SAH)
