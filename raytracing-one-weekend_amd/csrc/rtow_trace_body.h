@@ -822,6 +822,11 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     }
     const unsigned long long need_mask = __ballot(need_item);
     if (need_mask != 0ull) {
+      // The item-decoding parameters are read here from the kernel-argument segment (scalar loads)
+      // instead of living in SGPRs for the whole launch: the kernel is VALU-issue-bound and ran out
+      // of SGPRs, so every one of them cost a v_readlane (VALU) per use.
+      const RTOW_CONST TraceParams *kp = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kp));  // opaque per trip: keeps the loads from being hoisted out of the loop
       // Wave-local pool [pool_next, pool_end): one global atomic buys kItemBatch items,
       // which the lanes then take by ballot rank with no further traffic (a single hot
       // counter word saturates near 90 dequeues/us on this chip — one atomic per wave
@@ -834,7 +839,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         // guided self-scheduling: 64 items per atomic while the queue is long, shrinking to
         // exactly what this wave needs now as it drains (a wave that hoards items at the end
         // of the queue keeps the whole launch waiting: measured ~4 item durations per launch)
-        const unsigned long long left = (unsigned long long)P.n_items > seen ? (unsigned long long)P.n_items - seen : 0ull;
+        const unsigned long long left = (unsigned long long)kp->n_items > seen ? (unsigned long long)kp->n_items - seen : 0ull;
         uint32_t batch = (uint32_t)(left / ((unsigned long long)n_waves * 4ull));
         batch = batch > kItemBatch ? kItemBatch : batch;
         batch = batch < want - avail ? want - avail : batch;
@@ -845,14 +850,14 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         seen = base + batch;  // how far the queue had advanced when this wave last looked
         if (rank >= avail) mine = base + (rank - avail);
         const unsigned long long nn = base + (want - avail), ne = base + batch;
-        const unsigned long long cap = (unsigned long long)P.n_items;
+        const unsigned long long cap = (unsigned long long)kp->n_items;
         pool_next = (uint32_t)(nn < cap ? nn : cap);
         pool_end = (uint32_t)(ne < cap ? ne : cap);
       } else {
         pool_next += want;
       }
       if (need_item) {
-        if (mine >= (unsigned long long)P.n_items) {
+        if (mine >= (unsigned long long)kp->n_items) {
           done = true;
           if constexpr (STAMPS) {
             if (t_empty == 0ull) t_empty = __builtin_amdgcn_s_memrealtime();
@@ -860,27 +865,27 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         } else {
           // the queue is consumed from its far end: within a stream tiles run bottom-to-top, so
           // a launch ends on the (typically cheap) top of the image, not on its most expensive tiles
-          item = P.n_items - 1u - (uint32_t)mine;
-          const uint32_t k = fastdiv(item, P.div_npix);  // stream
+          item = kp->n_items - 1u - (uint32_t)mine;
+          const uint32_t k = fastdiv(item, FastDiv{kp->div_npix.magic, kp->div_npix.shift});  // stream
           const uint32_t lp = item - k * npix_local;     // local pixel
           uint32_t lr;
-          if (P.tile_h_log2 == 0u) {  // row-major
-            lr = fastdiv(lp, P.div_w);
-            j = lp - lr * (uint32_t)P.W;
+          if (kp->tile_h_log2 == 0u) {  // row-major
+            lr = fastdiv(lp, FastDiv{kp->div_w.magic, kp->div_w.shift});
+            j = lp - lr * (uint32_t)kp->W;
           } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile
             const uint32_t t = lp >> 6, w = lp & 63u;
-            const uint32_t tr = fastdiv(t, P.div_tpr);
-            const uint32_t tc = t - tr * (P.div_tpr_n);
-            lr = (tr << P.tile_h_log2) + (w >> P.tile_w_log2);
-            j = (tc << P.tile_w_log2) + (w & ((1u << P.tile_w_log2) - 1u));
+            const uint32_t tr = fastdiv(t, FastDiv{kp->div_tpr.magic, kp->div_tpr.shift});
+            const uint32_t tc = t - tr * (kp->div_tpr_n);
+            lr = (tr << kp->tile_h_log2) + (w >> kp->tile_w_log2);
+            j = (tc << kp->tile_w_log2) + (w & ((1u << kp->tile_w_log2) - 1u));
           }
           // local row -> global row: this rank's q-th strip is global strip q*nranks+rank
-          const uint32_t q = fastdiv(lr, P.div_tile);
-          const uint32_t rr = lr - q * (uint32_t)P.tile_rows;
-          gi = (q * (uint32_t)P.nranks + (uint32_t)P.rank) * (uint32_t)P.tile_rows + rr;
-          g.pixel = gi * (uint32_t)P.W + j;
-          g.sample = (k + (uint32_t)P.stream_first) * (uint32_t)P.spt;  // first sample index of this stream
-          s_left = P.spt;
+          const uint32_t q = fastdiv(lr, FastDiv{kp->div_tile.magic, kp->div_tile.shift});
+          const uint32_t rr = lr - q * (uint32_t)kp->tile_rows;
+          gi = (q * (uint32_t)kp->nranks + (uint32_t)kp->rank) * (uint32_t)kp->tile_rows + rr;
+          g.pixel = gi * (uint32_t)kp->W + j;
+          g.sample = (k + (uint32_t)kp->stream_first) * (uint32_t)kp->spt;  // first sample index of this stream
+          s_left = kp->spt;
           acc = {0.0, 0.0, 0.0};
         }
       }
