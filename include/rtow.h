@@ -231,10 +231,10 @@ int rtow_tonemap_device(rtow_ctx *ctx, const void *d_rgb_sums, int64_t n_values,
  * many launches that covers (the ring keeps the first 256 per collect). */
 int rtow_profile_collect(rtow_ctx *ctx, double *kernel_ms_sum, int32_t *launches);
 
-/* Diagnostic only: copies the 24 device counters of the last launch (see
+/* Diagnostic only: copies the 48 device counters of the last launch (see
  * csrc/rtow_trace_body.h; [8..12] are wave-cycle sums per region and [17..22] a histogram of
- * wave end times when the RTOW_STAMPS diagnostic kernel ran). */
-int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out24);
+ * wave end times, [29..33] the finer regions, when the RTOW_STAMPS diagnostic kernel ran). */
+int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out48);
 
 /* Convenience: upload + render + copy this rank's rows to host memory. */
 int rtow_render(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,

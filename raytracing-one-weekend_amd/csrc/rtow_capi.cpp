@@ -635,7 +635,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   const size_t depth_slots = (size_t)(cfg->max_child_rays > 0 ? cfg->max_child_rays : 1);
   if ((rc = c->partials.ensure((size_t)n_items * 3 * sizeof(double))) ||
       (rc = c->stack.ensure(depth_slots * (size_t)n_lanes * sizeof(uint32_t))) ||
-      (rc = c->counters.ensure(24 * sizeof(unsigned long long))))
+      (rc = c->counters.ensure(48 * sizeof(unsigned long long))))
     return rc;
 
   rtow::TraceParams P;
@@ -682,7 +682,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.t_origin = P.counters + 16;
 
   if (stats) HIPCHK(hipEventRecord(c->call_ev[0], st));
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, 24 * sizeof(unsigned long long), st));
+  HIPCHK(hipMemsetAsync(c->counters.p, 0, 48 * sizeof(unsigned long long), st));
   HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 5, 0xff, sizeof(unsigned long long), st));   // min end
   HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 16, 0xff, sizeof(unsigned long long), st));  // t_origin
   const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
@@ -737,12 +737,12 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
 
 // Diagnostic: the 16 device counters of the last launch (work queue, segments, prim
 // tests, node tests, ... region cycle sums of the RTOW_STAMPS build at [8..12]).
-int rtow_debug_counters(rtow_ctx *c, unsigned long long *out24) {
-  if (!c || !out24) return fail(RTOW_EINVAL, "NULL argument");
+int rtow_debug_counters(rtow_ctx *c, unsigned long long *out48) {
+  if (!c || !out48) return fail(RTOW_EINVAL, "NULL argument");
   if (!c->counters.p) return fail(RTOW_ENOSCENE, "no launch yet");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out24, c->counters.p, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out48, c->counters.p, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return RTOW_OK;
 }
 

@@ -12,6 +12,6 @@ np.save(out, img)
 print(out, "segments", st.segments, "samples", st.samples, "kernel_ms", st.kernel_ms)
 
 import ctypes as C
-buf = (C.c_ulonglong * 24)()
+buf = (C.c_ulonglong * 48)()
 rtow.lib().rtow_debug_counters(ctx._h, buf)
 print("take", buf[9], "release", buf[10], "gives", buf[11], "helps", buf[12], "hold", buf[13], "guard lanes", buf[14], "guard owners", buf[15])

@@ -15,15 +15,17 @@ else:
     cfg = rtow.make_config(1200, 800, 100, int(os.environ.get('RTOW_NSTREAMS', '10')), 50, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
 ctx = rtow.Context(0)
 img, st = ctx.render(scene, cfg)
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 48)()
 L = rtow.lib(); L.rtow_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 rtow.check(L.rtow_debug_counters(ctx._h, out))
 names = ["fetch", "regen", "walk-steps", "shade", "walk-leaves"]
-tot = sum(out[8:13]) or 1
+tot = (sum(out[8:13]) + sum(out[29:34])) or 1
 print(which, "kernel_ms(with stamps)", round(st.kernel_ms, 3), "Msamples/s", round(st.samples / st.kernel_ms / 1e3, 1),
       "segments", st.segments, "node/seg", round(st.node_tests / st.segments, 2), "prim/seg", round(st.prim_tests / st.segments, 2))
 for i, n in enumerate(names):
-    print(f"{n:6s} {out[8+i]/tot*100:5.1f}%")
+    print(f"{n:12s} {out[8+i]/tot*100:5.1f}%")
+for i, n in enumerate(["large list", "walk set-up", "hit record", "rejection", "sky+unwind"]):
+    print(f"{n:12s} {out[29+i]/tot*100:5.1f}%   (split out of walk-steps / shade)")
 iters, trips, phases = out[13], out[14], out[15]
 print(f"wave trips {trips}, step-loop iterations per trip {iters/max(trips,1):.1f}, leaf phases per trip {phases/max(trips,1):.2f}, "
       f"lane-segments per trip {st.segments/max(trips,1):.1f} of 64")
