@@ -1,6 +1,6 @@
 import sys, numpy as np
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent.parent
+ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "raytracing-one-weekend_amd"))
 import rtow
 ctx = rtow.Context(0)
