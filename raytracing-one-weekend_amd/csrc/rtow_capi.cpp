@@ -660,6 +660,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.div_npix = make_fastdiv((uint32_t)npix);
   P.div_w = make_fastdiv((uint32_t)cfg->image_width);
   P.div_tile = make_fastdiv((uint32_t)cfg->tile_rows);
+  P.div_ns = make_fastdiv((uint32_t)streams_now);
   // tile the pixel order when the geometry allows it (a tile never straddles two strips)
   uint32_t th = 0, tw = 0;
   if (!std::getenv("RTOW_NO_TILES")) {

@@ -78,6 +78,7 @@ struct TraceParams {
   uint32_t n_items;        // local_rows * W * nstreams
   uint32_t n_lanes;        // grid * block (stride of the path stack)
   FastDiv div_npix, div_w, div_tile;  // item -> (stream, row, column, strip)
+  FastDiv div_ns;                     // tiled order: (item / 64) -> (tile, stream)
   // pixel order inside this rank's rows: tiles of 2^tile_w_log2 x 2^tile_h_log2 = 64 pixels,
   // tiles row-major (tile_h_log2 == 0 and tile_w_log2 == 0: plain row-major order)
   uint32_t tile_w_log2, tile_h_log2;

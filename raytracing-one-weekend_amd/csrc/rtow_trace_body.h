@@ -863,22 +863,30 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             if (t_empty == 0ull) t_empty = __builtin_amdgcn_s_memrealtime();
           }
         } else {
-          // the queue is consumed from its far end: within a stream tiles run bottom-to-top, so
-          // a launch ends on the (typically cheap) top of the image, not on its most expensive tiles
-          item = kp->n_items - 1u - (uint32_t)mine;
-          const uint32_t k = fastdiv(item, FastDiv{kp->div_npix.magic, kp->div_npix.shift});  // stream
-          const uint32_t lp = item - k * npix_local;     // local pixel
-          uint32_t lr;
-          if (kp->tile_h_log2 == 0u) {  // row-major
+          // Queue order.  Tiled mode: tile-major, stream-minor — all streams of a 64-pixel tile are
+          // adjacent, tiles run top-to-bottom, and the queue is consumed from its far end, so a launch
+          // ENDS on the top of the image for every stream.  In the reference's scenes that is sky
+          // (one-segment paths): no 50-bounce path starts in the last moments of the launch, which is
+          // what the end-of-launch tail consists of.  (Stream-major order ended only the last
+          // stream on the sky.)  The partial-sum slot stays [stream][pixel].
+          const uint32_t qi = kp->n_items - 1u - (uint32_t)mine;
+          uint32_t k, lp, lr;
+          if (kp->tile_h_log2 == 0u) {  // row-major, stream-major
+            k = fastdiv(qi, FastDiv{kp->div_npix.magic, kp->div_npix.shift});
+            lp = qi - k * npix_local;
             lr = fastdiv(lp, FastDiv{kp->div_w.magic, kp->div_w.shift});
             j = lp - lr * (uint32_t)kp->W;
-          } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile
-            const uint32_t t = lp >> 6, w = lp & 63u;
+          } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile of one stream
+            const uint32_t g64 = qi >> 6, w = qi & 63u;
+            const uint32_t t = fastdiv(g64, FastDiv{kp->div_ns.magic, kp->div_ns.shift});
+            k = g64 - t * (uint32_t)kp->nstreams;
+            lp = (t << 6) | w;
             const uint32_t tr = fastdiv(t, FastDiv{kp->div_tpr.magic, kp->div_tpr.shift});
             const uint32_t tc = t - tr * (kp->div_tpr_n);
             lr = (tr << kp->tile_h_log2) + (w >> kp->tile_w_log2);
             j = (tc << kp->tile_w_log2) + (w & ((1u << kp->tile_w_log2) - 1u));
           }
+          item = k * npix_local + lp;  // partial-sum slot
           // local row -> global row: this rank's q-th strip is global strip q*nranks+rank
           const uint32_t q = fastdiv(lr, FastDiv{kp->div_tile.magic, kp->div_tile.shift});
           const uint32_t rr = lr - q * (uint32_t)kp->tile_rows;
