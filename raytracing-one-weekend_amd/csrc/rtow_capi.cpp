@@ -686,7 +686,6 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   HIPCHK(hipMemsetAsync(c->counters.p, 0, 48 * sizeof(unsigned long long), st));
   HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 5, 0xff, sizeof(unsigned long long), st));   // min end
   HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 16, 0xff, sizeof(unsigned long long), st));  // t_origin
-  HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 44, 0xff, sizeof(unsigned long long), st));  // diagnostic min
   const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
   if (slot >= 0) HIPCHK(hipEventRecord(c->ev[slot][0], st));
   int launch_kernel = kernel;

@@ -34,4 +34,3 @@ print(f"wave end times (ms after first wave start): mean {out[4]/nw/1e5:.3f}  mi
 
 print("waves by (end - own queue-empty time), 0.2 ms bins [0-0.2, .., 0.8-1.0, >=1.0]:", [int(out[17 + i]) for i in range(6)])
 print(f"max trips after queue-empty {int(out[40])}; stragglers (>= 0.4 ms): {int(out[43])} waves, mean trips {out[41]/max(out[43],1):.1f}, mean time {out[42]/max(out[43],1)/1e5:.3f} ms -> {out[42]/max(out[41],1)/100:.2f} us per trip")
-print(f"straggler waves: lane 0's last pixel row (from the top) min {int(out[44])} max {int(out[45])}")
