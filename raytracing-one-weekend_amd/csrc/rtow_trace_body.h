@@ -57,671 +57,12 @@
 
 namespace rtow {
 namespace {
-
-// Scene arrays are immutable during a launch: reading them through the constant
-// address space lets hipcc use scalar loads for wave-uniform indices.
-#define RTOW_CONST __attribute__((address_space(4)))
-typedef const RTOW_CONST double *cdptr;
-
-// Arithmetic type of rays, hit tests on small primitives and shading.  binary64 (the
-// reference's type) in the strict and fast builds; binary32 in the f32 build
-// (rtow_trace_f32.hip), where the always-test large primitives and all spheres met by the
-// STREAM/BVH kernels are still tested in binary64 (an r = 1000 sphere cancels catastrophically
-// in binary32: SURVEY.md §7 "fp32 robustness") and pixel sums stay binary64.
-#ifdef RTOW_REAL_F32
-typedef float real;
-#else
-typedef double real;
-#endif
-
-template <class T>
-struct Vec3 {
-  T x, y, z;
-};
-typedef Vec3<real> V3;
-typedef Vec3<double> V3d;
-template <class T>
-__device__ __forceinline__ Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-template <class T>
-__device__ __forceinline__ Vec3<T> operator-(Vec3<T> a, Vec3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-template <class T>
-__device__ __forceinline__ Vec3<T> operator-(Vec3<T> a) { return {-a.x, -a.y, -a.z}; }
-template <class T>
-__device__ __forceinline__ Vec3<T> operator*(Vec3<T> a, Vec3<T> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-template <class T>
-__device__ __forceinline__ Vec3<T> operator*(Vec3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
-template <class T>
-__device__ __forceinline__ Vec3<T> operator*(T s, Vec3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
-// glm: dot = x*x' + y*y' + z*z' (left to right); cross, normalize (v * 1/sqrt),
-// reflect (I - N*dot(N,I)*2), refract — same definitions as oracle/rtow_oracle.cpp.
-template <class T>
-__device__ __forceinline__ T dot(Vec3<T> a, Vec3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-template <class T>
-__device__ __forceinline__ Vec3<T> cross(Vec3<T> x, Vec3<T> y) {
-  return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
-}
-__device__ __forceinline__ V3d to_f64(Vec3<float> v) { return {(double)v.x, (double)v.y, (double)v.z}; }
-__device__ __forceinline__ V3d to_f64(V3d v) { return v; }
-#ifdef RTOW_FAST_MATH
-// fast build: hardware reciprocal-square-root seed (~2^-26) + two Newton steps instead of the
-// correctly rounded sqrt and division (relative error ~1e-16; the strict build keeps IEEE forms)
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
-  return y;
-}
-__device__ __forceinline__ double fast_sqrt(double x) { return x > 0.0 ? x * fast_rsqrt(x) : 0.0; }
-__device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = y * (2.0 - x * y);
-  y = y * (2.0 - x * y);
-  return y;
-}
-__device__ __forceinline__ double fast_div(double n, double d) { return n * fast_rcp(d); }
-#else
-__device__ __forceinline__ double fast_div(double n, double d) { return n / d; }
-__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
-__device__ __forceinline__ double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
-#endif
-// binary32 forms (f32 build only): hardware rsq/rcp/sqrt (1 ulp) + one Newton step where it is cheap
-__device__ __forceinline__ float fast_rsqrt(float x) {
-  float y = __builtin_amdgcn_rsqf(x);
-  return y * (1.5f - 0.5f * x * y * y);
-}
-__device__ __forceinline__ float fast_sqrt(float x) { return x > 0.0f ? __builtin_amdgcn_sqrtf(x) : 0.0f; }
-__device__ __forceinline__ float fast_rcp(float x) {
-  float y = __builtin_amdgcn_rcpf(x);
-  return y * (2.0f - x * y);
-}
-__device__ __forceinline__ float fast_div(float n, float d) { return n * fast_rcp(d); }
-template <class T>
-__device__ __forceinline__ Vec3<T> normalize(Vec3<T> v) { return v * fast_rsqrt(dot(v, v)); }
-template <class T>
-__device__ __forceinline__ Vec3<T> reflect(Vec3<T> I, Vec3<T> N) { return I - N * dot(N, I) * T(2.0); }
-template <class T>
-__device__ __forceinline__ Vec3<T> refract(Vec3<T> I, Vec3<T> N, T eta) {
-  T d = dot(N, I);
-  T k = T(1.0) - eta * eta * (T(1.0) - d * d);
-  if (k >= T(0.0)) return eta * I - (eta * d + fast_sqrt(k)) * N;
-  return {T(0.0), T(0.0), T(0.0)};
-}
-
-// ------------------------------------------------------------------ Philox ---
-struct Rng {
-  uint32_t pixel, sample, r;  // r = next request index of this sample
-};
-
-// Philox4x32-7: the fastest member of the family reported Crush-resistant (Salmon et al.,
-// SC'11); oracle/ uses the same round count (its tests pin the round function with the
-// published 10-round known answers).
-constexpr int kPhiloxRounds = 7;
-__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                           uint32_t k0, uint32_t k1, uint32_t &o0, uint32_t &o1,
-                                           uint32_t &o2, uint32_t &o3) {
-#pragma unroll
-  for (int r = 0; r < kPhiloxRounds; ++r) {
-    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    uint32_t n1 = (uint32_t)p1;
-    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-    uint32_t n3 = (uint32_t)p0;
-    c0 = n0;
-    c1 = n1;
-    c2 = n2;
-    c3 = n3;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-  o0 = c0;
-  o1 = c1;
-  o2 = c2;
-  o3 = c3;
-}
-
-// (w0 + w1*2^32) / 2^64 with double rounding steps, < 1 enforced
-__device__ __forceinline__ double canonical_from_words(uint32_t w0, uint32_t w1) {
-  double sum = (double)w0 + (double)w1 * 4294967296.0;
-  double r = sum * 0x1p-64;
-  if (r >= 1.0) r = 0x1.fffffffffffffp-1;
-  return r;
-}
-
-// One request = one block (w0..w3); see oracle/rtow_oracle.cpp, struct PhiloxDraw.
-// jitter + shutter time: 42 bits each (word k + 10 bits of word 3)
-__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, double &u,
-                                                  double &v, double &t) {
-  const double s42 = 0x1p-42;
-  u = ((double)o0 + (double)(o3 & 1023u) * 4294967296.0) * s42;
-  v = ((double)o1 + (double)((o3 >> 10) & 1023u) * 4294967296.0) * s42;
-  t = ((double)o2 + (double)((o3 >> 20) & 1023u) * 4294967296.0) * s42;
-}
-// binary32 build: the top 24 bits of the same 42-bit values (truncated, so < 1 and within one
-// binary32 ulp of the binary64 build's value: both builds sample the same lens/pixel positions)
-__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, float &u,
-                                                  float &v, float &t) {
-  u = (float)(((o3 & 1023u) << 14) | (o0 >> 18)) * 0x1p-24f;
-  v = (float)((((o3 >> 10) & 1023u) << 14) | (o1 >> 18)) * 0x1p-24f;
-  t = (float)((((o3 >> 20) & 1023u) << 14) | (o2 >> 18)) * 0x1p-24f;
-}
-__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, real &u, real &v, real &t) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
-  jitter_from_block(o0, o1, o2, o3, u, v, t);
-}
-// disk candidate: two doubles, each from two words like the reference's doubles
-__device__ __forceinline__ void rng_disk(Rng &g, uint32_t k0, uint32_t k1, real &a, real &b) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
-#ifdef RTOW_REAL_F32
-  a = (float)o1 * 0x1p-32f;  // the high words of the two doubles
-  b = (float)o3 * 0x1p-32f;
-#else
-  a = canonical_from_words(o0, o1);
-  b = canonical_from_words(o2, o3);
-#endif
-}
-// unit-ball candidate (32 bits per coordinate); the spare word is the dielectric coin of
-// the bounce when this is its first candidate
-__device__ __forceinline__ V3 rng_scatter(Rng &g, uint32_t k0, uint32_t k1, real &coin) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
-  const real s32 = real(0x1p-32);
-  coin = (real)o3 * s32;
-  return V3{(real)o0 * s32, (real)o1 * s32, (real)o2 * s32};
-}
-
-// -------------------------------------------------------- primitive hit tests ---
-struct Closest {
-  real t;    // closest accepted root so far (the shrinking tmax of src/render.cpp:57-65)
-  int prim;  // class-major primitive id, -1 = miss
-};
-
-// sphere_hit_helper up to the accepted root (src/common-model.cpp:70-81);
-// the hit point and normal are computed once, for the winner only.
-// `inv_a` is 1/a, used only by the fast build (one reciprocal per ray instead of two
-// divisions per candidate hit); the strict build divides like the reference.
-// T is the arithmetic of the test: `real`, or double for large primitives in the f32 build.
-__device__ __forceinline__ double rabs(double x) { return fabs(x); }
-__device__ __forceinline__ float rabs(float x) { return fabsf(x); }
-
-template <class T>
-__device__ __forceinline__ T sphere_disc(Vec3<T> o, Vec3<T> d, T a, T cx, T cy, T cz, T r2, T &h) {
-  Vec3<T> oc = {o.x - cx, o.y - cy, o.z - cz};
-  h = dot(oc, d);
-  T c = dot(oc, oc) - rabs(r2);  // r2 carries the radius' sign (see rtow_capi.cpp)
-  return h * h - a * c;
-}
-
-template <class T>
-__device__ __forceinline__ void sphere_resolve(T disc, T h, T a, T inv_a, int id, T tmin, Closest &best) {
-  if (disc >= T(0.0)) {
-    T sq = fast_sqrt(disc);
-#if defined(RTOW_FAST_MATH)
-    T root = (-h - sq) * inv_a;
-    const T root2 = (-h + sq) * inv_a;
-#else
-    (void)inv_a;
-    T root = (-h - sq) / a;
-#endif
-    bool ok = true;
-    if (root < tmin || root > (T)best.t) {
-#if defined(RTOW_FAST_MATH)
-      root = root2;
-#else
-      root = (-h + sq) / a;
-#endif
-      if (root < tmin || root > (T)best.t) ok = false;
-    }
-    if (ok) {
-      best.t = (real)root;
-      best.prim = id;
-    }
-  }
-}
-
-template <class T>
-__device__ __forceinline__ void sphere_test(Vec3<T> o, Vec3<T> d, T a, T inv_a, T cx, T cy, T cz, T r2, int id,
-                                            T tmin, Closest &best) {
-  T h;
-  const T disc = sphere_disc(o, d, a, cx, cy, cz, r2, h);
-  sphere_resolve(disc, h, a, inv_a, id, tmin, best);
-}
-
-// Triangle::hit (src/common-model.cpp:103-125) with e1, e2, n precomputed
-template <class T>
-__device__ __forceinline__ void triangle_test(Vec3<T> o, Vec3<T> d, Vec3<T> A, Vec3<T> e1, Vec3<T> e2, Vec3<T> n,
-                                              int id, T tmin, Closest &best) {
-  T det = -dot(d, n);
-  T invdet = fast_rcp(det);  // strict build: 1.0 / det
-  Vec3<T> ao = o - A;
-  Vec3<T> dao = cross(ao, d);
-  T u = dot(e2, dao) * invdet;
-  T v = -dot(e1, dao) * invdet;
-  T t = dot(ao, n) * invdet;
-  if (det >= T(1e-6) && t >= tmin && t <= (T)best.t && u >= T(0.0) && v >= T(0.0) && (u + v) <= T(1.0)) {
-    best.t = (real)t;
-    best.prim = id;
-  }
-}
-
-#define RTOW_TMIN 0.001  // src/render.cpp:33
-
-// ------------------------------------------------------- closest hit: STREAM ---
-// Always binary64 (in the f32 build the ray is widened once per segment): this kernel is for
-// scenes of <= 16 primitives, which include the r = 1000 ground sphere.
-__device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3d o, V3d d, double time) {
-  Closest best;
-  best.t = (real)__builtin_huge_val();  // tmax = +inf, src/render.cpp:34
-  best.prim = -1;
-  const double tmin = RTOW_TMIN;
-  const double a = dot(d, d);
-  const double inv_a = fast_rcp(a);  // used by the fast build only
-  {
-    cdptr g = (cdptr)sc.sph;
-    const int n = sc.n_sph;
-#pragma unroll 4
-    for (int i = 0; i < n; ++i) {
-      sphere_test<double>(o, d, a, inv_a, g[4 * i + 0], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], i, tmin, best);
-    }
-  }
-  {
-    cdptr g = (cdptr)sc.mov;
-    const int n = sc.n_mov;
-    const int base = sc.n_sph;
-#pragma unroll 2
-    for (int i = 0; i < n; ++i) {
-      // center(time) = c0 + time*(c1-c0), src/oo-primitives.h:64-66 with t0=0, t1=1
-      double cx = g[8 * i + 0] + time * g[8 * i + 3];
-      double cy = g[8 * i + 1] + time * g[8 * i + 4];
-      double cz = g[8 * i + 2] + time * g[8 * i + 5];
-      sphere_test<double>(o, d, a, inv_a, cx, cy, cz, g[8 * i + 6], base + i, tmin, best);
-    }
-  }
-  {
-    cdptr g = (cdptr)sc.tri;
-    const int n = sc.n_tri;
-    const int base = sc.n_sph + sc.n_mov;
-#pragma unroll 2
-    for (int i = 0; i < n; ++i) {
-      V3d A = {g[12 * i + 0], g[12 * i + 1], g[12 * i + 2]};
-      V3d e1 = {g[12 * i + 3], g[12 * i + 4], g[12 * i + 5]};
-      V3d e2 = {g[12 * i + 6], g[12 * i + 7], g[12 * i + 8]};
-      V3d nn = {g[12 * i + 9], g[12 * i + 10], g[12 * i + 11]};
-      triangle_test<double>(o, d, A, e1, e2, nn, base + i, tmin, best);
-    }
-  }
-  return best;
-}
-
-// Diagnostic region stamps (STAMPS build only, never in a timed run): wave cycles per
-// region of the main loop, accumulated in scalar registers and added to
-// counters[8 + region] once per wave.  Shares, not absolute times (each stamp drains
-// the wave's outstanding memory operations).
-enum { RG_FETCH = 0, RG_REGEN, RG_WALK, RG_SHADE, RG_LEAF, RG_COUNT };
-template <bool ON>
-struct Stamps {
-  unsigned long long t[RG_COUNT] = {0, 0, 0, 0, 0};
-  unsigned long long last = 0;
-  unsigned long long iters = 0, trips = 0, phases = 0;  // wave-level loop counts
-  __device__ __forceinline__ void start() {
-    if constexpr (ON) last = now();
-  }
-  __device__ __forceinline__ void mark(int region) {
-    if constexpr (ON) {
-      const unsigned long long n = now();
-      t[region] += n - last;
-      last = n;
-    }
-  }
-  static __device__ __forceinline__ unsigned long long now() {
-    unsigned long long v;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return v;
-  }
-};
-
-// ---------------------------------------------------------- closest hit: BVH ---
-extern __shared__ __align__(16) unsigned char rtow_lds[];
-
-// Scene image reader: LDS copy (ds_read_b128/b64) or the global blob (L1/L2).
-template <bool LDS>
-struct Image {
-  const unsigned char *g;
-  __device__ __forceinline__ float4 f4(uint32_t off) const {
-    if constexpr (LDS)
-      return *reinterpret_cast<const float4 *>(rtow_lds + off);
-    else
-      return *reinterpret_cast<const float4 *>(g + off);
-  }
-  __device__ __forceinline__ double2 d2(uint32_t off) const {
-    if constexpr (LDS)
-      return *reinterpret_cast<const double2 *>(rtow_lds + off);
-    else
-      return *reinterpret_cast<const double2 *>(g + off);
-  }
-  __device__ __forceinline__ uint32_t u32(uint32_t off) const {
-    if constexpr (LDS)
-      return *reinterpret_cast<const uint32_t *>(rtow_lds + off);
-    else
-      return *reinterpret_cast<const uint32_t *>(g + off);
-  }
-};
-
-__device__ __forceinline__ float round_up_f32(double t) { return __double2float_ru(t); }
-__device__ __forceinline__ float round_up_f32(float t) { return t; }
-
-__device__ __forceinline__ float safe_inv(float d) {
-  // axis-parallel rays: a huge finite reciprocal keeps the fma slab form free of NaNs
-  const float big = 1e30f;
-  return fabsf(d) < 1e-30f ? (__builtin_signbitf(d) ? -big : big) : 1.0f / d;
-}
-
-struct ImgOffsets {  // byte offsets of the id and record sections inside a scene image
-  uint32_t ids, sph, mov, tri;
-  uint32_t sph32, mov32;  // f32 build: binary32 copies of the sphere records (grid cells); `tri` then
-                          // points at binary32 triangle records (48 B), the only triangle section
-};
-
-// The ray of one segment in the forms the tests need.  In the binary64 builds the two forms
-// are the same values; in the f32 build the ray is widened once per segment for the tests
-// that must run in binary64.
-struct RayForms {
-  V3 o, d;
-  real a, inv_a, time;
-  V3d o64, d64;
-  double a64, inv_a64, time64;
-};
-__device__ __forceinline__ RayForms make_ray_forms(V3 o, V3 d, real time) {
-  RayForms r;
-  r.o = o;
-  r.d = d;
-  r.time = time;
-  r.a = dot(d, d);
-  r.inv_a = fast_rcp(r.a);  // used by the fast builds only
-  r.o64 = to_f64(o);
-  r.d64 = to_f64(d);
-  r.time64 = (double)time;
-#ifdef RTOW_REAL_F32
-  r.a64 = dot(r.d64, r.d64);
-  r.inv_a64 = fast_rcp(r.a64);
-#else
-  r.a64 = r.a;
-  r.inv_a64 = r.inv_a;
-#endif
-  return r;
-}
-
-// Tests primitives ids[first .. first+count) of a scene image against the ray (the same code
-// as the STREAM kernel, so the accepted (t, primitive) is the same).  SMALL: the spheres are
-// grid-cell members, tested in binary32 by the f32 build (no effect in the binary64 builds).
-template <bool LDS, bool SMALL>
-__device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, ImgOffsets off,
-                                          uint32_t first, uint32_t count, const RayForms &ray, Closest &best,
-                                          uint32_t &nprim, int &last_id) {
-  for (uint32_t k = 0; k < count; ++k) {
-    const int id = (int)im.u32(off.ids + 4u * (first + k));
-    // one-entry mailbox: a primitive spanning adjacent grid cells is listed in each of them
-    if (id == last_id) continue;
-    last_id = id;
-    ++nprim;
-    if (id < sc.n_sph) {
-#ifdef RTOW_REAL_F32
-      if constexpr (SMALL) {
-        const float4 p = im.f4(off.sph32 + 16u * (uint32_t)id);
-        sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p.x, p.y, p.z, p.w, id, (float)RTOW_TMIN, best);
-        continue;
-      }
-#endif
-      const uint32_t r = off.sph + 32u * (uint32_t)id;
-      const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
-      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
-    } else if (id < sc.n_sph + sc.n_mov) {
-#ifdef RTOW_REAL_F32
-      if constexpr (SMALL) {
-        const uint32_t r = off.mov32 + 32u * (uint32_t)(id - sc.n_sph);
-        const float4 p0 = im.f4(r), p1 = im.f4(r + 16u);  // c0xyz dx | dy dz r2 -
-        sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p0.x + ray.time * p0.w, p0.y + ray.time * p1.x,
-                           p0.z + ray.time * p1.y, p1.z, id, (float)RTOW_TMIN, best);
-        continue;
-      }
-#endif
-      const uint32_t r = off.mov + 64u * (uint32_t)(id - sc.n_sph);
-      const double2 p0 = im.d2(r), p1 = im.d2(r + 16u), p2 = im.d2(r + 32u), p3 = im.d2(r + 48u);
-      const double cx = p0.x + ray.time64 * p1.y;
-      const double cy = p0.y + ray.time64 * p2.x;
-      const double cz = p1.x + ray.time64 * p2.y;
-      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
-    } else {
-#ifdef RTOW_REAL_F32
-      const uint32_t r = off.tri + 48u * (uint32_t)(id - sc.n_sph - sc.n_mov);
-      const float4 q0 = im.f4(r), q1 = im.f4(r + 16u), q2 = im.f4(r + 32u);  // A e1 | e1 e2 | e2 n
-      triangle_test<float>(ray.o, ray.d, V3{q0.x, q0.y, q0.z}, V3{q0.w, q1.x, q1.y}, V3{q1.z, q1.w, q2.x},
-                           V3{q2.y, q2.z, q2.w}, id, (float)RTOW_TMIN, best);
-#else
-      const uint32_t r = off.tri + 96u * (uint32_t)(id - sc.n_sph - sc.n_mov);
-      const double2 q0 = im.d2(r), q1 = im.d2(r + 16u), q2 = im.d2(r + 32u), q3 = im.d2(r + 48u),
-                    q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
-      triangle_test<double>(ray.o64, ray.d64, V3d{q0.x, q0.y, q1.x}, V3d{q1.y, q2.x, q2.y}, V3d{q3.x, q3.y, q4.x},
-                            V3d{q4.y, q5.x, q5.y}, id, RTOW_TMIN, best);
-#endif
-    }
-  }
-}
-
-template <bool LDS, bool ST>
-__device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const DevScene &sc, V3 o,
-                                                   V3 d, real time, bool active, uint32_t &nnode,
-                                                   uint32_t &nprim, Stamps<ST> &stamps) {
-  Closest best;
-  best.t = (real)__builtin_huge_val();
-  best.prim = -1;
-  const RayForms ray = make_ray_forms(o, d, time);
-  // f32 copy of the ray for the (conservative) box tests
-  const float ix = safe_inv((float)d.x), iy = safe_inv((float)d.y), iz = safe_inv((float)d.z);
-  const float oix = (float)o.x * ix, oiy = (float)o.y * iy, oiz = (float)o.z * iz;
-  const float tmin32 = 0.0009f;   // < RTOW_TMIN
-  const float slack = 1.00002f;   // relative slack on the far side of the interval
-  float tmax32 = __builtin_huge_valf();
-  const uint32_t END = (uint32_t)sc.n_nodes;  // skip links past the last node point here
-  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri, sc.off_sph32, sc.off_mov32};
-  int last_id = -1;
-  uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
-  uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u;  // queued leaves (0 = empty), oldest first
-  // Termination: every link of the image points forward (node+1 or skip > node, checked
-  // by the host at upload) and the walk stops at any index >= END, so a lane takes at
-  // most n_nodes steps.  (A per-trip guard counter here cost 7 % of the kernel.)
-  for (;;) {
-    if constexpr (ST) stamps.iters += 1;
-    if (node < END) {
-      const float4 r0 = im.f4(node * 32u), r1 = im.f4(node * 32u + 16u);
-      ++nnode;
-      const float ax = fmaf(r0.x, ix, -oix), bx = fmaf(r0.w, ix, -oix);
-      const float ay = fmaf(r0.y, iy, -oiy), by = fmaf(r1.x, iy, -oiy);
-      const float az = fmaf(r0.z, iz, -oiz), bz = fmaf(r1.y, iz, -oiz);
-      const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
-      const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax32));
-      const bool hit = tnear <= tfar * slack;
-      const uint32_t skip = __float_as_uint(r1.z), leaf = __float_as_uint(r1.w);
-      if (hit && leaf != 0u) {
-        if (q0 == 0u)
-          q0 = leaf;
-        else if (q1 == 0u)
-          q1 = leaf;
-        else if (q2 == 0u)
-          q2 = leaf;
-        else
-          q3 = leaf;
-      }
-      node = (hit && leaf == 0u) ? node + 1u : skip;
-    }
-    const bool any_walking = __any(node < END);
-    if (__any(q3 != 0u) || !any_walking) {
-      stamps.mark(RG_WALK);
-      if constexpr (ST) stamps.phases += 1;
-      // leaf phase: every lane tests the primitives of the OLDEST leaf it queued (most
-      // lanes hold one; only the lanes whose queue filled hold two, and theirs moves up)
-      if (q0 != 0u) leaf_test<LDS, false>(im, sc, off, q0 >> 3, q0 & 7u, ray, best, nprim, last_id);
-      q0 = q1;
-      q1 = q2;
-      q2 = q3;
-      q3 = 0u;
-      // shrink the f32 interval (rounded up: never below the f64 value)
-      tmax32 = round_up_f32(best.t);
-      stamps.mark(RG_LEAF);
-      if (!any_walking && !__any(q0 != 0u)) break;
-    }
-  }
-  return best;
-}
-
-// --------------------------------------------------------- closest hit: GRID ---
-// 3D-DDA over the uniform grid of rtow_grid.h.  Primitives far larger than the rest (the
-// ground sphere) are not in the grid; every ray tests that short list first.  Cells are
-// visited in order along the ray; a non-empty cell is queued like a BVH leaf and tested in
-// the SIMT-dense leaf phase.  The walk ends when the ray leaves the grid (integer cell
-// counters, so at most nx+ny+nz steps whatever the floats do) or when the exit distance of
-// the current cell is beyond the closest hit so far.
-template <bool LDS, bool ST>
-__device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const DevScene &sc, V3 o,
-                                                    V3 d, real time, bool active, uint32_t &nnode,
-                                                    uint32_t &nprim, Stamps<ST> &stamps) {
-  Closest best;
-  best.t = (real)__builtin_huge_val();
-  best.prim = -1;
-  const RayForms ray = make_ray_forms(o, d, time);
-  const ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri, sc.g_off_sph32, sc.g_off_mov32};
-  int last_id = -1;
-  // header: wave-uniform scalar loads from the global copy of the image
-  const RTOW_CONST float *hf = (const RTOW_CONST float *)sc.gblob;
-  const RTOW_CONST int32_t *hi = (const RTOW_CONST int32_t *)sc.gblob;
-  const float gx = hf[0], gy = hf[1], gz = hf[2];
-  const float cx = hf[3], cy = hf[4], cz = hf[5];
-  const float icx = hf[6], icy = hf[7], icz = hf[8];
-  const int nx = hi[9], ny = hi[10], nz = hi[11];
-  const uint32_t n_large = (uint32_t)hi[12], off_large = (uint32_t)hi[13];
-
-  // the large primitives, for every ray.  Static spheres are taken four (then two) at a time:
-  // all records are loaded and all discriminants computed before any hit branch, so LDS
-  // latency and the f64 dependency chains of one test overlap the others.
-  if (active && n_large != 0u) {
-    const uint32_t lf = (off_large - off.ids) >> 2;
-    uint32_t k = 0;
-    for (; k + 3 < n_large; k += 4) {
-      int id[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) id[j] = (int)im.u32(off.ids + 4u * (lf + k + j));
-      if (id[0] < sc.n_sph && id[1] < sc.n_sph && id[2] < sc.n_sph && id[3] < sc.n_sph) {
-        double dd[4], hh[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t r = off.sph + 32u * (uint32_t)id[j];
-          const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
-          dd[j] = sphere_disc<double>(ray.o64, ray.d64, ray.a64, p0.x, p0.y, p1.x, p1.y, hh[j]);
-        }
-        nprim += 4u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sphere_resolve<double>(dd[j], hh[j], ray.a64, ray.inv_a64, id[j], RTOW_TMIN, best);
-        last_id = id[3];
-      } else {
-        leaf_test<LDS, false>(im, sc, off, lf + k, 4u, ray, best, nprim, last_id);
-      }
-    }
-    for (; k + 1 < n_large; k += 2) {
-      const int ia = (int)im.u32(off.ids + 4u * (lf + k)), ib = (int)im.u32(off.ids + 4u * (lf + k + 1));
-      if (ia < sc.n_sph && ib < sc.n_sph) {
-        const uint32_t ra = off.sph + 32u * (uint32_t)ia, rb = off.sph + 32u * (uint32_t)ib;
-        const double2 a0 = im.d2(ra), a1 = im.d2(ra + 16u), b0 = im.d2(rb), b1 = im.d2(rb + 16u);
-        double ha, hb;
-        const double da = sphere_disc<double>(ray.o64, ray.d64, ray.a64, a0.x, a0.y, a1.x, a1.y, ha);
-        const double db = sphere_disc<double>(ray.o64, ray.d64, ray.a64, b0.x, b0.y, b1.x, b1.y, hb);
-        nprim += 2u;
-        sphere_resolve<double>(da, ha, ray.a64, ray.inv_a64, ia, RTOW_TMIN, best);
-        sphere_resolve<double>(db, hb, ray.a64, ray.inv_a64, ib, RTOW_TMIN, best);
-        last_id = ib;
-      } else {
-        leaf_test<LDS, false>(im, sc, off, lf + k, 2u, ray, best, nprim, last_id);
-      }
-    }
-    if (k < n_large) leaf_test<LDS, false>(im, sc, off, lf + k, n_large - k, ray, best, nprim, last_id);
-  }
-  float tmax32 = round_up_f32(best.t);
-
-  // clip the ray to the grid bounds (f32, conservative by the padding of rtow_grid.h)
-  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
-  const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-  const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-  const float oix = ox * ix, oiy = oy * iy, oiz = oz * iz;
-  const float hx = fmaf((float)nx, cx, gx), hy = fmaf((float)ny, cy, gy), hz = fmaf((float)nz, cz, gz);
-  const float ax = fmaf(gx, ix, -oix), bx = fmaf(hx, ix, -oix);
-  const float ay = fmaf(gy, iy, -oiy), by = fmaf(hy, iy, -oiy);
-  const float az = fmaf(gz, iz, -oiz), bz = fmaf(hz, iz, -oiz);
-  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0009f));
-  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax32));
-  bool walking = active && t0 <= t1 * 1.00002f;
-
-  // starting cell and DDA state
-  const float px = fmaf(t0, dx, ox), py = fmaf(t0, dy, oy), pz = fmaf(t0, dz, oz);
-  int c0 = (int)floorf((px - gx) * icx), c1 = (int)floorf((py - gy) * icy), c2 = (int)floorf((pz - gz) * icz);
-  c0 = min(max(c0, 0), nx - 1);
-  c1 = min(max(c1, 0), ny - 1);
-  c2 = min(max(c2, 0), nz - 1);
-  const bool fx = dx >= 0.0f, fy = dy >= 0.0f, fz = dz >= 0.0f;
-  float tmx = fmaf(fmaf((float)(c0 + (fx ? 1 : 0)), cx, gx), ix, -oix);
-  float tmy = fmaf(fmaf((float)(c1 + (fy ? 1 : 0)), cy, gy), iy, -oiy);
-  float tmz = fmaf(fmaf((float)(c2 + (fz ? 1 : 0)), cz, gz), iz, -oiz);
-  const float tdx = fabsf(cx * ix), tdy = fabsf(cy * iy), tdz = fabsf(cz * iz);
-  int remx = fx ? nx - 1 - c0 : c0, remy = fy ? ny - 1 - c1 : c1, remz = fz ? nz - 1 - c2 : c2;
-  const int incx = fx ? 1 : -1, incy = fy ? nx : -nx, incz = fz ? nx * ny : -(nx * ny);
-  int idx = (c2 * ny + c1) * nx + c0;
-
-  uint32_t q0 = 0u, q1 = 0u;
-  for (;;) {
-    if constexpr (ST) stamps.iters += 1;
-    if (walking) {
-      const uint32_t cw = im.u32(sc.g_off_cells + 4u * (uint32_t)idx);
-      ++nnode;
-      if (cw != 0u) {
-        if (q0 == 0u)
-          q0 = cw;
-        else
-          q1 = cw;
-      }
-      // leave through the nearest cell wall
-      const bool sx = tmx <= tmy && tmx <= tmz;
-      const bool sy = !sx && tmy <= tmz;
-      const float tnext = sx ? tmx : (sy ? tmy : tmz);
-      const int rem = sx ? remx : (sy ? remy : remz);
-      walking = rem > 0 && !(tnext > tmax32);
-      idx += sx ? incx : (sy ? incy : incz);
-      tmx += sx ? tdx : 0.0f;
-      tmy += sy ? tdy : 0.0f;
-      tmz += (!sx && !sy) ? tdz : 0.0f;
-      remx -= sx ? 1 : 0;
-      remy -= sy ? 1 : 0;
-      remz -= (!sx && !sy) ? 1 : 0;
-    }
-    const bool any_walking = __any(walking);
-    if (__any(q1 != 0u) || !any_walking) {
-      stamps.mark(RG_WALK);
-      if constexpr (ST) stamps.phases += 1;
-      if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
-      q0 = q1;
-      q1 = 0u;
-      tmax32 = round_up_f32(best.t);
-      stamps.mark(RG_LEAF);
-      if (!any_walking && !__any(q0 != 0u)) break;
-    }
-  }
-  return best;
-}
+#include "rtow_trace_math.h"
+#include "rtow_trace_rng.h"
+#include "rtow_trace_hit.h"
+#include "rtow_trace_stamps.h"
+#include "rtow_trace_bvh.h"
+#include "rtow_trace_grid.h"
 
 // --------------------------------------------------------------- the kernel ---
 // n / d for a divisor fixed per launch: q = (((n - t) >> 1) + t) >> shift, t = mulhi(n, magic)
@@ -1324,3 +665,4 @@ int RTOW_CAT(trace_occupancy_, RTOW_SUFFIX)(int kernel, int block, unsigned lds_
 }
 
 }  // namespace rtow
+

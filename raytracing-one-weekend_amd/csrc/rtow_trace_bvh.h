@@ -1,0 +1,197 @@
+// rtow_trace_bvh.h — part of the trace kernels (included by rtow_trace_body.h inside namespace rtow::{anonymous};
+// see that file for the execution model).  Scene-image reader, leaf tests and the threaded BVH walk.
+#pragma once
+// ---------------------------------------------------------- closest hit: BVH ---
+extern __shared__ __align__(16) unsigned char rtow_lds[];
+
+// Scene image reader: LDS copy (ds_read_b128/b64) or the global blob (L1/L2).
+template <bool LDS>
+struct Image {
+  const unsigned char *g;
+  __device__ __forceinline__ float4 f4(uint32_t off) const {
+    if constexpr (LDS)
+      return *reinterpret_cast<const float4 *>(rtow_lds + off);
+    else
+      return *reinterpret_cast<const float4 *>(g + off);
+  }
+  __device__ __forceinline__ double2 d2(uint32_t off) const {
+    if constexpr (LDS)
+      return *reinterpret_cast<const double2 *>(rtow_lds + off);
+    else
+      return *reinterpret_cast<const double2 *>(g + off);
+  }
+  __device__ __forceinline__ uint32_t u32(uint32_t off) const {
+    if constexpr (LDS)
+      return *reinterpret_cast<const uint32_t *>(rtow_lds + off);
+    else
+      return *reinterpret_cast<const uint32_t *>(g + off);
+  }
+};
+
+__device__ __forceinline__ float round_up_f32(double t) { return __double2float_ru(t); }
+__device__ __forceinline__ float round_up_f32(float t) { return t; }
+
+__device__ __forceinline__ float safe_inv(float d) {
+  // axis-parallel rays: a huge finite reciprocal keeps the fma slab form free of NaNs
+  const float big = 1e30f;
+  return fabsf(d) < 1e-30f ? (__builtin_signbitf(d) ? -big : big) : 1.0f / d;
+}
+
+struct ImgOffsets {  // byte offsets of the id and record sections inside a scene image
+  uint32_t ids, sph, mov, tri;
+  uint32_t sph32, mov32;  // f32 build: binary32 copies of the sphere records (grid cells); `tri` then
+                          // points at binary32 triangle records (48 B), the only triangle section
+};
+
+// The ray of one segment in the forms the tests need.  In the binary64 builds the two forms
+// are the same values; in the f32 build the ray is widened once per segment for the tests
+// that must run in binary64.
+struct RayForms {
+  V3 o, d;
+  real a, inv_a, time;
+  V3d o64, d64;
+  double a64, inv_a64, time64;
+};
+__device__ __forceinline__ RayForms make_ray_forms(V3 o, V3 d, real time) {
+  RayForms r;
+  r.o = o;
+  r.d = d;
+  r.time = time;
+  r.a = dot(d, d);
+  r.inv_a = fast_rcp(r.a);  // used by the fast builds only
+  r.o64 = to_f64(o);
+  r.d64 = to_f64(d);
+  r.time64 = (double)time;
+#ifdef RTOW_REAL_F32
+  r.a64 = dot(r.d64, r.d64);
+  r.inv_a64 = fast_rcp(r.a64);
+#else
+  r.a64 = r.a;
+  r.inv_a64 = r.inv_a;
+#endif
+  return r;
+}
+
+// Tests primitives ids[first .. first+count) of a scene image against the ray (the same code
+// as the STREAM kernel, so the accepted (t, primitive) is the same).  SMALL: the spheres are
+// grid-cell members, tested in binary32 by the f32 build (no effect in the binary64 builds).
+template <bool LDS, bool SMALL>
+__device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, ImgOffsets off,
+                                          uint32_t first, uint32_t count, const RayForms &ray, Closest &best,
+                                          uint32_t &nprim, int &last_id) {
+  for (uint32_t k = 0; k < count; ++k) {
+    const int id = (int)im.u32(off.ids + 4u * (first + k));
+    // one-entry mailbox: a primitive spanning adjacent grid cells is listed in each of them
+    if (id == last_id) continue;
+    last_id = id;
+    ++nprim;
+    if (id < sc.n_sph) {
+#ifdef RTOW_REAL_F32
+      if constexpr (SMALL) {
+        const float4 p = im.f4(off.sph32 + 16u * (uint32_t)id);
+        sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p.x, p.y, p.z, p.w, id, (float)RTOW_TMIN, best);
+        continue;
+      }
+#endif
+      const uint32_t r = off.sph + 32u * (uint32_t)id;
+      const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
+      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+    } else if (id < sc.n_sph + sc.n_mov) {
+#ifdef RTOW_REAL_F32
+      if constexpr (SMALL) {
+        const uint32_t r = off.mov32 + 32u * (uint32_t)(id - sc.n_sph);
+        const float4 p0 = im.f4(r), p1 = im.f4(r + 16u);  // c0xyz dx | dy dz r2 -
+        sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p0.x + ray.time * p0.w, p0.y + ray.time * p1.x,
+                           p0.z + ray.time * p1.y, p1.z, id, (float)RTOW_TMIN, best);
+        continue;
+      }
+#endif
+      const uint32_t r = off.mov + 64u * (uint32_t)(id - sc.n_sph);
+      const double2 p0 = im.d2(r), p1 = im.d2(r + 16u), p2 = im.d2(r + 32u), p3 = im.d2(r + 48u);
+      const double cx = p0.x + ray.time64 * p1.y;
+      const double cy = p0.y + ray.time64 * p2.x;
+      const double cz = p1.x + ray.time64 * p2.y;
+      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
+    } else {
+#ifdef RTOW_REAL_F32
+      const uint32_t r = off.tri + 48u * (uint32_t)(id - sc.n_sph - sc.n_mov);
+      const float4 q0 = im.f4(r), q1 = im.f4(r + 16u), q2 = im.f4(r + 32u);  // A e1 | e1 e2 | e2 n
+      triangle_test<float>(ray.o, ray.d, V3{q0.x, q0.y, q0.z}, V3{q0.w, q1.x, q1.y}, V3{q1.z, q1.w, q2.x},
+                           V3{q2.y, q2.z, q2.w}, id, (float)RTOW_TMIN, best);
+#else
+      const uint32_t r = off.tri + 96u * (uint32_t)(id - sc.n_sph - sc.n_mov);
+      const double2 q0 = im.d2(r), q1 = im.d2(r + 16u), q2 = im.d2(r + 32u), q3 = im.d2(r + 48u),
+                    q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
+      triangle_test<double>(ray.o64, ray.d64, V3d{q0.x, q0.y, q1.x}, V3d{q1.y, q2.x, q2.y}, V3d{q3.x, q3.y, q4.x},
+                            V3d{q4.y, q5.x, q5.y}, id, RTOW_TMIN, best);
+#endif
+    }
+  }
+}
+
+template <bool LDS, bool ST>
+__device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const DevScene &sc, V3 o,
+                                                   V3 d, real time, bool active, uint32_t &nnode,
+                                                   uint32_t &nprim, Stamps<ST> &stamps) {
+  Closest best;
+  best.t = (real)__builtin_huge_val();
+  best.prim = -1;
+  const RayForms ray = make_ray_forms(o, d, time);
+  // f32 copy of the ray for the (conservative) box tests
+  const float ix = safe_inv((float)d.x), iy = safe_inv((float)d.y), iz = safe_inv((float)d.z);
+  const float oix = (float)o.x * ix, oiy = (float)o.y * iy, oiz = (float)o.z * iz;
+  const float tmin32 = 0.0009f;   // < RTOW_TMIN
+  const float slack = 1.00002f;   // relative slack on the far side of the interval
+  float tmax32 = __builtin_huge_valf();
+  const uint32_t END = (uint32_t)sc.n_nodes;  // skip links past the last node point here
+  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri, sc.off_sph32, sc.off_mov32};
+  int last_id = -1;
+  uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
+  uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u;  // queued leaves (0 = empty), oldest first
+  // Termination: every link of the image points forward (node+1 or skip > node, checked
+  // by the host at upload) and the walk stops at any index >= END, so a lane takes at
+  // most n_nodes steps.  (A per-trip guard counter here cost 7 % of the kernel.)
+  for (;;) {
+    if constexpr (ST) stamps.iters += 1;
+    if (node < END) {
+      const float4 r0 = im.f4(node * 32u), r1 = im.f4(node * 32u + 16u);
+      ++nnode;
+      const float ax = fmaf(r0.x, ix, -oix), bx = fmaf(r0.w, ix, -oix);
+      const float ay = fmaf(r0.y, iy, -oiy), by = fmaf(r1.x, iy, -oiy);
+      const float az = fmaf(r0.z, iz, -oiz), bz = fmaf(r1.y, iz, -oiz);
+      const float tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
+      const float tfar = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax32));
+      const bool hit = tnear <= tfar * slack;
+      const uint32_t skip = __float_as_uint(r1.z), leaf = __float_as_uint(r1.w);
+      if (hit && leaf != 0u) {
+        if (q0 == 0u)
+          q0 = leaf;
+        else if (q1 == 0u)
+          q1 = leaf;
+        else if (q2 == 0u)
+          q2 = leaf;
+        else
+          q3 = leaf;
+      }
+      node = (hit && leaf == 0u) ? node + 1u : skip;
+    }
+    const bool any_walking = __any(node < END);
+    if (__any(q3 != 0u) || !any_walking) {
+      stamps.mark(RG_WALK);
+      if constexpr (ST) stamps.phases += 1;
+      // leaf phase: every lane tests the primitives of the OLDEST leaf it queued (most
+      // lanes hold one; only the lanes whose queue filled hold two, and theirs moves up)
+      if (q0 != 0u) leaf_test<LDS, false>(im, sc, off, q0 >> 3, q0 & 7u, ray, best, nprim, last_id);
+      q0 = q1;
+      q1 = q2;
+      q2 = q3;
+      q3 = 0u;
+      // shrink the f32 interval (rounded up: never below the f64 value)
+      tmax32 = round_up_f32(best.t);
+      stamps.mark(RG_LEAF);
+      if (!any_walking && !__any(q0 != 0u)) break;
+    }
+  }
+  return best;
+}
+

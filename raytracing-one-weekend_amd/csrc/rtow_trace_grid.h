@@ -1,0 +1,144 @@
+// rtow_trace_grid.h — part of the trace kernels (included by rtow_trace_body.h inside namespace rtow::{anonymous};
+// see that file for the execution model).  The uniform-grid (3D-DDA) walk.
+#pragma once
+// --------------------------------------------------------- closest hit: GRID ---
+// 3D-DDA over the uniform grid of rtow_grid.h.  Primitives far larger than the rest (the
+// ground sphere) are not in the grid; every ray tests that short list first.  Cells are
+// visited in order along the ray; a non-empty cell is queued like a BVH leaf and tested in
+// the SIMT-dense leaf phase.  The walk ends when the ray leaves the grid (integer cell
+// counters, so at most nx+ny+nz steps whatever the floats do) or when the exit distance of
+// the current cell is beyond the closest hit so far.
+template <bool LDS, bool ST>
+__device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const DevScene &sc, V3 o,
+                                                    V3 d, real time, bool active, uint32_t &nnode,
+                                                    uint32_t &nprim, Stamps<ST> &stamps) {
+  Closest best;
+  best.t = (real)__builtin_huge_val();
+  best.prim = -1;
+  const RayForms ray = make_ray_forms(o, d, time);
+  const ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri, sc.g_off_sph32, sc.g_off_mov32};
+  int last_id = -1;
+  // header: wave-uniform scalar loads from the global copy of the image
+  const RTOW_CONST float *hf = (const RTOW_CONST float *)sc.gblob;
+  const RTOW_CONST int32_t *hi = (const RTOW_CONST int32_t *)sc.gblob;
+  const float gx = hf[0], gy = hf[1], gz = hf[2];
+  const float cx = hf[3], cy = hf[4], cz = hf[5];
+  const float icx = hf[6], icy = hf[7], icz = hf[8];
+  const int nx = hi[9], ny = hi[10], nz = hi[11];
+  const uint32_t n_large = (uint32_t)hi[12], off_large = (uint32_t)hi[13];
+
+  // the large primitives, for every ray.  Static spheres are taken four (then two) at a time:
+  // all records are loaded and all discriminants computed before any hit branch, so LDS
+  // latency and the f64 dependency chains of one test overlap the others.
+  if (active && n_large != 0u) {
+    const uint32_t lf = (off_large - off.ids) >> 2;
+    uint32_t k = 0;
+    for (; k + 3 < n_large; k += 4) {
+      int id[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) id[j] = (int)im.u32(off.ids + 4u * (lf + k + j));
+      if (id[0] < sc.n_sph && id[1] < sc.n_sph && id[2] < sc.n_sph && id[3] < sc.n_sph) {
+        double dd[4], hh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t r = off.sph + 32u * (uint32_t)id[j];
+          const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
+          dd[j] = sphere_disc<double>(ray.o64, ray.d64, ray.a64, p0.x, p0.y, p1.x, p1.y, hh[j]);
+        }
+        nprim += 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sphere_resolve<double>(dd[j], hh[j], ray.a64, ray.inv_a64, id[j], RTOW_TMIN, best);
+        last_id = id[3];
+      } else {
+        leaf_test<LDS, false>(im, sc, off, lf + k, 4u, ray, best, nprim, last_id);
+      }
+    }
+    for (; k + 1 < n_large; k += 2) {
+      const int ia = (int)im.u32(off.ids + 4u * (lf + k)), ib = (int)im.u32(off.ids + 4u * (lf + k + 1));
+      if (ia < sc.n_sph && ib < sc.n_sph) {
+        const uint32_t ra = off.sph + 32u * (uint32_t)ia, rb = off.sph + 32u * (uint32_t)ib;
+        const double2 a0 = im.d2(ra), a1 = im.d2(ra + 16u), b0 = im.d2(rb), b1 = im.d2(rb + 16u);
+        double ha, hb;
+        const double da = sphere_disc<double>(ray.o64, ray.d64, ray.a64, a0.x, a0.y, a1.x, a1.y, ha);
+        const double db = sphere_disc<double>(ray.o64, ray.d64, ray.a64, b0.x, b0.y, b1.x, b1.y, hb);
+        nprim += 2u;
+        sphere_resolve<double>(da, ha, ray.a64, ray.inv_a64, ia, RTOW_TMIN, best);
+        sphere_resolve<double>(db, hb, ray.a64, ray.inv_a64, ib, RTOW_TMIN, best);
+        last_id = ib;
+      } else {
+        leaf_test<LDS, false>(im, sc, off, lf + k, 2u, ray, best, nprim, last_id);
+      }
+    }
+    if (k < n_large) leaf_test<LDS, false>(im, sc, off, lf + k, n_large - k, ray, best, nprim, last_id);
+  }
+  float tmax32 = round_up_f32(best.t);
+
+  // clip the ray to the grid bounds (f32, conservative by the padding of rtow_grid.h)
+  const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+  const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+  const float oix = ox * ix, oiy = oy * iy, oiz = oz * iz;
+  const float hx = fmaf((float)nx, cx, gx), hy = fmaf((float)ny, cy, gy), hz = fmaf((float)nz, cz, gz);
+  const float ax = fmaf(gx, ix, -oix), bx = fmaf(hx, ix, -oix);
+  const float ay = fmaf(gy, iy, -oiy), by = fmaf(hy, iy, -oiy);
+  const float az = fmaf(gz, iz, -oiz), bz = fmaf(hz, iz, -oiz);
+  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0009f));
+  const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax32));
+  bool walking = active && t0 <= t1 * 1.00002f;
+
+  // starting cell and DDA state
+  const float px = fmaf(t0, dx, ox), py = fmaf(t0, dy, oy), pz = fmaf(t0, dz, oz);
+  int c0 = (int)floorf((px - gx) * icx), c1 = (int)floorf((py - gy) * icy), c2 = (int)floorf((pz - gz) * icz);
+  c0 = min(max(c0, 0), nx - 1);
+  c1 = min(max(c1, 0), ny - 1);
+  c2 = min(max(c2, 0), nz - 1);
+  const bool fx = dx >= 0.0f, fy = dy >= 0.0f, fz = dz >= 0.0f;
+  float tmx = fmaf(fmaf((float)(c0 + (fx ? 1 : 0)), cx, gx), ix, -oix);
+  float tmy = fmaf(fmaf((float)(c1 + (fy ? 1 : 0)), cy, gy), iy, -oiy);
+  float tmz = fmaf(fmaf((float)(c2 + (fz ? 1 : 0)), cz, gz), iz, -oiz);
+  const float tdx = fabsf(cx * ix), tdy = fabsf(cy * iy), tdz = fabsf(cz * iz);
+  int remx = fx ? nx - 1 - c0 : c0, remy = fy ? ny - 1 - c1 : c1, remz = fz ? nz - 1 - c2 : c2;
+  const int incx = fx ? 1 : -1, incy = fy ? nx : -nx, incz = fz ? nx * ny : -(nx * ny);
+  int idx = (c2 * ny + c1) * nx + c0;
+
+  uint32_t q0 = 0u, q1 = 0u;
+  for (;;) {
+    if constexpr (ST) stamps.iters += 1;
+    if (walking) {
+      const uint32_t cw = im.u32(sc.g_off_cells + 4u * (uint32_t)idx);
+      ++nnode;
+      if (cw != 0u) {
+        if (q0 == 0u)
+          q0 = cw;
+        else
+          q1 = cw;
+      }
+      // leave through the nearest cell wall
+      const bool sx = tmx <= tmy && tmx <= tmz;
+      const bool sy = !sx && tmy <= tmz;
+      const float tnext = sx ? tmx : (sy ? tmy : tmz);
+      const int rem = sx ? remx : (sy ? remy : remz);
+      walking = rem > 0 && !(tnext > tmax32);
+      idx += sx ? incx : (sy ? incy : incz);
+      tmx += sx ? tdx : 0.0f;
+      tmy += sy ? tdy : 0.0f;
+      tmz += (!sx && !sy) ? tdz : 0.0f;
+      remx -= sx ? 1 : 0;
+      remy -= sy ? 1 : 0;
+      remz -= (!sx && !sy) ? 1 : 0;
+    }
+    const bool any_walking = __any(walking);
+    if (__any(q1 != 0u) || !any_walking) {
+      stamps.mark(RG_WALK);
+      if constexpr (ST) stamps.phases += 1;
+      if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
+      q0 = q1;
+      q1 = 0u;
+      tmax32 = round_up_f32(best.t);
+      stamps.mark(RG_LEAF);
+      if (!any_walking && !__any(q0 != 0u)) break;
+    }
+  }
+  return best;
+}
+

@@ -1,0 +1,126 @@
+// rtow_trace_hit.h — part of the trace kernels (included by rtow_trace_body.h inside namespace rtow::{anonymous};
+// see that file for the execution model).  Sphere and triangle hit tests (templated on the arithmetic of the test) and the STREAM closest hit.
+#pragma once
+// -------------------------------------------------------- primitive hit tests ---
+struct Closest {
+  real t;    // closest accepted root so far (the shrinking tmax of src/render.cpp:57-65)
+  int prim;  // class-major primitive id, -1 = miss
+};
+
+// sphere_hit_helper up to the accepted root (src/common-model.cpp:70-81);
+// the hit point and normal are computed once, for the winner only.
+// `inv_a` is 1/a, used only by the fast build (one reciprocal per ray instead of two
+// divisions per candidate hit); the strict build divides like the reference.
+// T is the arithmetic of the test: `real`, or double for large primitives in the f32 build.
+__device__ __forceinline__ double rabs(double x) { return fabs(x); }
+__device__ __forceinline__ float rabs(float x) { return fabsf(x); }
+
+template <class T>
+__device__ __forceinline__ T sphere_disc(Vec3<T> o, Vec3<T> d, T a, T cx, T cy, T cz, T r2, T &h) {
+  Vec3<T> oc = {o.x - cx, o.y - cy, o.z - cz};
+  h = dot(oc, d);
+  T c = dot(oc, oc) - rabs(r2);  // r2 carries the radius' sign (see rtow_capi.cpp)
+  return h * h - a * c;
+}
+
+template <class T>
+__device__ __forceinline__ void sphere_resolve(T disc, T h, T a, T inv_a, int id, T tmin, Closest &best) {
+  if (disc >= T(0.0)) {
+    T sq = fast_sqrt(disc);
+#if defined(RTOW_FAST_MATH)
+    T root = (-h - sq) * inv_a;
+    const T root2 = (-h + sq) * inv_a;
+#else
+    (void)inv_a;
+    T root = (-h - sq) / a;
+#endif
+    bool ok = true;
+    if (root < tmin || root > (T)best.t) {
+#if defined(RTOW_FAST_MATH)
+      root = root2;
+#else
+      root = (-h + sq) / a;
+#endif
+      if (root < tmin || root > (T)best.t) ok = false;
+    }
+    if (ok) {
+      best.t = (real)root;
+      best.prim = id;
+    }
+  }
+}
+
+template <class T>
+__device__ __forceinline__ void sphere_test(Vec3<T> o, Vec3<T> d, T a, T inv_a, T cx, T cy, T cz, T r2, int id,
+                                            T tmin, Closest &best) {
+  T h;
+  const T disc = sphere_disc(o, d, a, cx, cy, cz, r2, h);
+  sphere_resolve(disc, h, a, inv_a, id, tmin, best);
+}
+
+// Triangle::hit (src/common-model.cpp:103-125) with e1, e2, n precomputed
+template <class T>
+__device__ __forceinline__ void triangle_test(Vec3<T> o, Vec3<T> d, Vec3<T> A, Vec3<T> e1, Vec3<T> e2, Vec3<T> n,
+                                              int id, T tmin, Closest &best) {
+  T det = -dot(d, n);
+  T invdet = fast_rcp(det);  // strict build: 1.0 / det
+  Vec3<T> ao = o - A;
+  Vec3<T> dao = cross(ao, d);
+  T u = dot(e2, dao) * invdet;
+  T v = -dot(e1, dao) * invdet;
+  T t = dot(ao, n) * invdet;
+  if (det >= T(1e-6) && t >= tmin && t <= (T)best.t && u >= T(0.0) && v >= T(0.0) && (u + v) <= T(1.0)) {
+    best.t = (real)t;
+    best.prim = id;
+  }
+}
+
+#define RTOW_TMIN 0.001  // src/render.cpp:33
+
+// ------------------------------------------------------- closest hit: STREAM ---
+// Always binary64 (in the f32 build the ray is widened once per segment): this kernel is for
+// scenes of <= 16 primitives, which include the r = 1000 ground sphere.
+__device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3d o, V3d d, double time) {
+  Closest best;
+  best.t = (real)__builtin_huge_val();  // tmax = +inf, src/render.cpp:34
+  best.prim = -1;
+  const double tmin = RTOW_TMIN;
+  const double a = dot(d, d);
+  const double inv_a = fast_rcp(a);  // used by the fast build only
+  {
+    cdptr g = (cdptr)sc.sph;
+    const int n = sc.n_sph;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+      sphere_test<double>(o, d, a, inv_a, g[4 * i + 0], g[4 * i + 1], g[4 * i + 2], g[4 * i + 3], i, tmin, best);
+    }
+  }
+  {
+    cdptr g = (cdptr)sc.mov;
+    const int n = sc.n_mov;
+    const int base = sc.n_sph;
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) {
+      // center(time) = c0 + time*(c1-c0), src/oo-primitives.h:64-66 with t0=0, t1=1
+      double cx = g[8 * i + 0] + time * g[8 * i + 3];
+      double cy = g[8 * i + 1] + time * g[8 * i + 4];
+      double cz = g[8 * i + 2] + time * g[8 * i + 5];
+      sphere_test<double>(o, d, a, inv_a, cx, cy, cz, g[8 * i + 6], base + i, tmin, best);
+    }
+  }
+  {
+    cdptr g = (cdptr)sc.tri;
+    const int n = sc.n_tri;
+    const int base = sc.n_sph + sc.n_mov;
+#pragma unroll 2
+    for (int i = 0; i < n; ++i) {
+      V3d A = {g[12 * i + 0], g[12 * i + 1], g[12 * i + 2]};
+      V3d e1 = {g[12 * i + 3], g[12 * i + 4], g[12 * i + 5]};
+      V3d e2 = {g[12 * i + 6], g[12 * i + 7], g[12 * i + 8]};
+      V3d nn = {g[12 * i + 9], g[12 * i + 10], g[12 * i + 11]};
+      triangle_test<double>(o, d, A, e1, e2, nn, base + i, tmin, best);
+    }
+  }
+  return best;
+}
+

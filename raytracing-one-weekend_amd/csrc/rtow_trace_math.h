@@ -1,0 +1,94 @@
+// rtow_trace_math.h — part of the trace kernels (included by rtow_trace_body.h inside namespace rtow::{anonymous};
+// see that file for the execution model).  Arithmetic type `real`, vector math, fast/strict sqrt, reciprocal and division.
+#pragma once
+
+// Scene arrays are immutable during a launch: reading them through the constant
+// address space lets hipcc use scalar loads for wave-uniform indices.
+#define RTOW_CONST __attribute__((address_space(4)))
+typedef const RTOW_CONST double *cdptr;
+
+// Arithmetic type of rays, hit tests on small primitives and shading.  binary64 (the
+// reference's type) in the strict and fast builds; binary32 in the f32 build
+// (rtow_trace_f32.hip), where the always-test large primitives and all spheres met by the
+// STREAM/BVH kernels are still tested in binary64 (an r = 1000 sphere cancels catastrophically
+// in binary32: SURVEY.md §7 "fp32 robustness") and pixel sums stay binary64.
+#ifdef RTOW_REAL_F32
+typedef float real;
+#else
+typedef double real;
+#endif
+
+template <class T>
+struct Vec3 {
+  T x, y, z;
+};
+typedef Vec3<real> V3;
+typedef Vec3<double> V3d;
+template <class T>
+__device__ __forceinline__ Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator-(Vec3<T> a, Vec3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator-(Vec3<T> a) { return {-a.x, -a.y, -a.z}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator*(Vec3<T> a, Vec3<T> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator*(Vec3<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class T>
+__device__ __forceinline__ Vec3<T> operator*(T s, Vec3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+// glm: dot = x*x' + y*y' + z*z' (left to right); cross, normalize (v * 1/sqrt),
+// reflect (I - N*dot(N,I)*2), refract — same definitions as oracle/rtow_oracle.cpp.
+template <class T>
+__device__ __forceinline__ T dot(Vec3<T> a, Vec3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T>
+__device__ __forceinline__ Vec3<T> cross(Vec3<T> x, Vec3<T> y) {
+  return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
+}
+__device__ __forceinline__ V3d to_f64(Vec3<float> v) { return {(double)v.x, (double)v.y, (double)v.z}; }
+__device__ __forceinline__ V3d to_f64(V3d v) { return v; }
+#ifdef RTOW_FAST_MATH
+// fast build: hardware reciprocal-square-root seed (~2^-26) + two Newton steps instead of the
+// correctly rounded sqrt and division (relative error ~1e-16; the strict build keeps IEEE forms)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x) { return x > 0.0 ? x * fast_rsqrt(x) : 0.0; }
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  y = y * (2.0 - x * y);
+  return y;
+}
+__device__ __forceinline__ double fast_div(double n, double d) { return n * fast_rcp(d); }
+#else
+__device__ __forceinline__ double fast_div(double n, double d) { return n / d; }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+__device__ __forceinline__ double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
+#endif
+// binary32 forms (f32 build only): hardware rsq/rcp/sqrt (1 ulp) + one Newton step where it is cheap
+__device__ __forceinline__ float fast_rsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  return y * (1.5f - 0.5f * x * y * y);
+}
+__device__ __forceinline__ float fast_sqrt(float x) { return x > 0.0f ? __builtin_amdgcn_sqrtf(x) : 0.0f; }
+__device__ __forceinline__ float fast_rcp(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  return y * (2.0f - x * y);
+}
+__device__ __forceinline__ float fast_div(float n, float d) { return n * fast_rcp(d); }
+template <class T>
+__device__ __forceinline__ Vec3<T> normalize(Vec3<T> v) { return v * fast_rsqrt(dot(v, v)); }
+template <class T>
+__device__ __forceinline__ Vec3<T> reflect(Vec3<T> I, Vec3<T> N) { return I - N * dot(N, I) * T(2.0); }
+template <class T>
+__device__ __forceinline__ Vec3<T> refract(Vec3<T> I, Vec3<T> N, T eta) {
+  T d = dot(N, I);
+  T k = T(1.0) - eta * eta * (T(1.0) - d * d);
+  if (k >= T(0.0)) return eta * I - (eta * d + fast_sqrt(k)) * N;
+  return {T(0.0), T(0.0), T(0.0)};
+}
+
