@@ -32,7 +32,8 @@ static void usage(const char *argv0) {
                "  --precision strict|fast|f32 f64 without / with FMA contraction (default fast); f32 = binary32 preview\n"
                "  --kernel auto|brute|bvh|grid  closest-hit strategy (default auto)\n"
                "  --builder host|device       BVH build: host SAH (default) or on the GPU (LBVH)\n"
-               "  --p6                        binary P6 output, write_color on the device\n";
+               "  --p6                        binary P6 output, write_color on the device\n"
+               "  --general-obj               with -l: load every shape and fan-triangulate polygons\n";
 }
 
 int main(int argc, char *argv[]) {
@@ -85,6 +86,8 @@ int main(int argc, char *argv[]) {
         else throw std::runtime_error("--precision: strict|fast|f32");
       } else if (std::strcmp(a, "--p6") == 0) {
         opt.binary_ppm = true;
+      } else if (std::strcmp(a, "--general-obj") == 0) {
+        opt.general_obj = true;
       } else if (std::strcmp(a, "--builder") == 0) {
         const std::string v = value();
         if (v == "host") opt.builder = 0;

@@ -31,6 +31,9 @@ struct DeviceOptions {
   int kernel = 0;     // RTOW_KERNEL_AUTO
   int builder = -1;   // -1: the context's default (RTOW_BUILDER env); 0 host SAH, 1 device LBVH
   bool binary_ppm = false;  // P6 (write_color runs on the device) instead of the reference's P3 text
+  // OBJ input beyond the reference's (which reads shapes[0] only and throws on a face that is not a
+  // triangle, src/main.cpp:115-133): every shape of the file, polygons fan-triangulated
+  bool general_obj = false;
 };
 DeviceOptions &device_options();
 

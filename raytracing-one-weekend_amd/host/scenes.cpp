@@ -77,7 +77,7 @@ struct ObjMesh {
   std::vector<std::vector<long>> faces;  // 0-based vertex indices
 };
 
-static ObjMesh load_obj_first_shape(const std::string &path) {
+static ObjMesh load_obj(const std::string &path, bool all_shapes) {
   std::FILE *f = std::fopen(path.c_str(), "r");
   if (!f) throw std::runtime_error("Can't load because cannot open " + path);
   ObjMesh m;
@@ -113,7 +113,7 @@ static ObjMesh load_obj_first_shape(const std::string &path) {
         while (*q && *q != ' ' && *q != '\t' && *q != '\n' && *q != '\r') ++q;  // skip /vt/vn
       }
       m.faces.push_back(std::move(idx));
-    } else if ((p[0] == 'o' || p[0] == 'g') && sep && seen_face) {
+    } else if ((p[0] == 'o' || p[0] == 'g') && sep && seen_face && !all_shapes) {
       break;  // only shapes[0], src/main.cpp:115
     }
   }
@@ -131,11 +131,19 @@ Scene foo(const Config &cfg) {
   rt::Scene world{cam};
   auto &boring_material = world.boutique().add<rt::Lambertian>(rt::color{0.5, 0.5, 0.5});
 
-  const ObjMesh mesh = load_obj_first_shape(cfg.model.value());
+  // (RTOW_GENERAL_OBJ=1: the same for hosts that build scenes through rtow_host_scene_obj)
+  const char *genv = std::getenv("RTOW_GENERAL_OBJ");
+  const bool general = device_options().general_obj || (genv && genv[0] == '1');
+  const ObjMesh mesh = load_obj(cfg.model.value(), general);
   for (const auto &face : mesh.faces) {
     if (face.size() == 3) {
       world.primitives().add<rt::Triangle>(mesh.vertices[face[0]], mesh.vertices[face[1]],
                                            mesh.vertices[face[2]], boring_material);
+    } else if (general && face.size() > 3) {
+      // fan triangulation (v0, vi, vi+1), the order tinyobjloader's triangulate uses for convex faces
+      for (size_t i = 1; i + 1 < face.size(); ++i)
+        world.primitives().add<rt::Triangle>(mesh.vertices[face[0]], mesh.vertices[face[i]],
+                                             mesh.vertices[face[i + 1]], boring_material);
     } else {
       throw std::runtime_error("Oops found a face that isn't a triangle");
     }

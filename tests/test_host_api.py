@@ -116,3 +116,21 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(line["value"] - samples / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
     c = line["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == "Msamples/s"
+
+
+def test_general_obj_loads_all_shapes_and_triangulates(tmp_path, monkeypatch):
+    """Beyond the reference (which reads shapes[0] only and throws on a quad, src/main.cpp:115-133):
+    RTOW_GENERAL_OBJ=1 / --general-obj loads every shape and fan-triangulates polygons; relative
+    (negative) indices resolve against the vertices read so far."""
+    obj = tmp_path / "two_shapes.obj"
+    obj.write_text("o first\nv -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nf 1 2 3 4\n"
+                   "o second\nv -1 -1 -1\nv 1 -1 -1\nv 0 1 -1\nf -3 -2 -1\n")
+    with pytest.raises(Exception):
+        rtow.HostScene.obj(obj)  # reference behaviour: a quad is an error
+    monkeypatch.setenv("RTOW_GENERAL_OBJ", "1")
+    sc = rtow.HostScene.obj(obj)
+    assert sc.c.n_triangles == 3
+    tri = np.ctypeslib.as_array(sc.c.triangle_geom, shape=(3, 9))
+    assert np.array_equal(tri[0], [-1, -1, 0, 1, -1, 0, 1, 1, 0])      # fan: (v0, v1, v2)
+    assert np.array_equal(tri[1], [-1, -1, 0, 1, 1, 0, -1, 1, 0])      #      (v0, v2, v3)
+    assert np.array_equal(tri[2], [-1, -1, -1, 1, -1, -1, 0, 1, -1])   # second shape, relative indices
