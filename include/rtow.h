@@ -180,7 +180,9 @@ int rtow_scene_upload(rtow_ctx *ctx, const rtow_scene_t *scene);
  * src/render.cpp:73-110, which runs on the host inside render()):
  *   HOST_SAH    binned surface-area-heuristic build on the host (default; best tree)
  *   DEVICE_LBVH Morton codes + radix sort + Karras' radix tree + refit, all on the GPU
- *               (csrc/rtow_build.hip) — for scenes rebuilt every frame
+ *               (csrc/rtow_build.hip) — for scenes rebuilt every frame; the uniform grid of the
+ *               GRID kernel is then built on the GPU too (csrc/rtow_build_grid.hip, byte-identical
+ *               to the host-built image)
  * Images are bit-identical with either builder (the closest hit is tree-independent).
  * Takes effect at the next upload; the environment variable RTOW_BUILDER=host|device sets the
  * default of new contexts. */
@@ -235,6 +237,11 @@ int rtow_profile_collect(rtow_ctx *ctx, double *kernel_ms_sum, int32_t *launches
  * csrc/rtow_trace_body.h; [8..12] are wave-cycle sums per region and [17..22] a histogram of
  * wave end times, [29..33] the finer regions, when the RTOW_STAMPS diagnostic kernel ran). */
 int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out48);
+
+/* Diagnostic only: copies a resident scene image to the host (which: 0 BVH image, 1 grid image,
+ * 2 / 3 the same of the RTOW_F32 build).  `out` NULL: size query.  The tests compare host-built
+ * and device-built images byte for byte with it. */
+int rtow_debug_image(rtow_ctx *ctx, int32_t which, void *out, int64_t capacity, int64_t *size_out);
 
 /* Convenience: upload + render + copy this rank's rows to host memory. */
 int rtow_render(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,

@@ -156,6 +156,21 @@ int lbvh_build(const double *sph, const double *sph_r, const double *mov, const 
                void **handle, int *n_nodes);
 int lbvh_emit(void *handle, int leaf_max, unsigned char *blob_dev, uint32_t off_ids, int n_nodes, void *stream);
 void lbvh_release(void *handle);
+// csrc/rtow_build_grid.hip
+struct GridBuildBounds {
+  double gmn[3], gmx[3];
+  double scale_prims;
+  int32_t n_small, n_large;
+};
+int grid_build_phase1(const double *sph, const double *sph_r, const double *mov, const double *tri, int ns, int nm,
+                      int nt, double time0, double time1, double large_ratio, void *stream, void **handle,
+                      GridBuildBounds *out);
+int grid_build_phase2(void *handle, const float gminf[3], const float cellf[3], const int32_t n[3], double pad,
+                      void *stream, unsigned long long *total_ids, unsigned long long *max_list);
+int grid_build_phase3(void *handle, const float gminf[3], const float cellf[3], const int32_t n[3], double pad,
+                      unsigned long long total_ids, unsigned char *blob_dev, uint32_t off_cells, uint32_t off_ids,
+                      void *stream);
+void grid_build_release(void *handle);
 }  // namespace rtow
 
 struct rtow_ctx {
@@ -175,6 +190,7 @@ struct rtow_ctx {
   long long bvh_nodes = 0;
   int builder = RTOW_BUILDER_HOST_SAH;
   void *lbvh_scratch = nullptr;  // device builder's buffers, kept across uploads
+  void *grid_scratch = nullptr;
   rtow_build_info_t build_info{};
   // workspace
   DevBuf partials, stack, counters;
@@ -235,6 +251,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   }
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   rtow::lbvh_release(c->lbvh_scratch);
+  rtow::grid_build_release(c->grid_scratch);
   delete c;
 }
 
@@ -388,15 +405,55 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   // skip the host build, a GRID request then falls back to the BVH
   int grid_max_tris = 8192;
   if (const char *e = std::getenv("RTOW_GRID_MAX_TRIS")) grid_max_tris = std::atoi(e);
-  if (nt <= grid_max_tris)
+  bool grid_on_device = false;
+  if (nt <= grid_max_tris && c->builder == RTOW_BUILDER_DEVICE_LBVH) {
+    // the same grid, built in HBM (csrc/rtow_build_grid.hip); the host does the scalar steps between
+    // the phases with the code the host builder uses, so the image is byte-identical
+    grid_on_device = true;
+    rtow::GridBuildBounds gb;
+    int grc = rtow::grid_build_phase1((const double *)c->sph.p, (const double *)c->sph_r.p, (const double *)c->mov.p,
+                                      (const double *)c->tri.p, ns, nm, nt, s->camera.t0, s->camera.t1, large_ratio,
+                                      nullptr, &c->grid_scratch, &gb);
+    if (grc) return fail(RTOW_EHIP, "device grid build failed (phase 1, stage %d): %s", grc, hipGetErrorString(hipGetLastError()));
+    if (gb.n_small > 0 && gb.n_large <= 64) {
+      rtow::GridHeader hd;
+      rtow::grid_header(gb.gmn, gb.gmx, gb.scale_prims, s->camera.origin, (size_t)gb.n_small, cpp, hd);
+      unsigned long long total_ids = 0, max_list = 0;
+      grc = rtow::grid_build_phase2(c->grid_scratch, hd.gminf, hd.cellf, hd.n, hd.pad, nullptr, &total_ids, &max_list);
+      if (grc) return fail(RTOW_EHIP, "device grid build failed (phase 2, stage %d): %s", grc, hipGetErrorString(hipGetLastError()));
+      if (max_list <= 255 && total_ids + (unsigned long long)gb.n_large < (1u << 24)) {
+        const size_t ncell = (size_t)hd.n[0] * hd.n[1] * hd.n[2];
+        for (int k = 0; k < 3; ++k) gimg.n[k] = hd.n[k];
+        rtow::layout_grid_image(ncell, (size_t)total_ids + (size_t)gb.n_large, (size_t)gb.n_large, sph, mov, tri, pmat,
+                                mats_bytes, gimg, true);
+        if ((rc = c->gblob.ensure(gimg.total_bytes))) return rc;
+        unsigned char *gp = (unsigned char *)c->gblob.p;
+        unsigned char header[64];
+        const uint32_t off_large = (uint32_t)(gimg.off_ids + total_ids * 4);
+        rtow::write_grid_header(header, hd, gimg.n_large, off_large);
+        HIPCHK(hipMemsetAsync(gp, 0, gimg.total_bytes, nullptr));
+        HIPCHK(hipMemcpyAsync(gp, header, 64, hipMemcpyHostToDevice, nullptr));
+        if (ns) HIPCHK(hipMemcpyAsync(gp + gimg.off_sph, c->sph.p, sph.size() * 8, hipMemcpyDeviceToDevice, nullptr));
+        if (nm) HIPCHK(hipMemcpyAsync(gp + gimg.off_mov, c->mov.p, mov.size() * 8, hipMemcpyDeviceToDevice, nullptr));
+        if (nt) HIPCHK(hipMemcpyAsync(gp + gimg.off_tri, c->tri.p, tri.size() * 8, hipMemcpyDeviceToDevice, nullptr));
+        HIPCHK(hipMemcpyAsync(gp + gimg.off_pmat, c->prim_mat.p, pmat.size() * 4, hipMemcpyDeviceToDevice, nullptr));
+        HIPCHK(hipMemcpyAsync(gp + gimg.off_mats, c->mats.p, mats_bytes.size(), hipMemcpyDeviceToDevice, nullptr));
+        grc = rtow::grid_build_phase3(c->grid_scratch, hd.gminf, hd.cellf, hd.n, hd.pad, total_ids, gp, gimg.off_cells,
+                                      gimg.off_ids, nullptr);
+        if (grc) return fail(RTOW_EHIP, "device grid build failed (phase 3, stage %d): %s", grc, hipGetErrorString(hipGetLastError()));
+        gimg.ok = true;
+      }
+    }
+  } else if (nt <= grid_max_tris) {
     rtow::build_grid_image(sph, sph_r, mov, tri, s->camera.origin, gimg, cpp, large_ratio, s->camera.t0,
                            s->camera.t1, pmat, mats_bytes);
+  }
   const double t_grid1 = now_ms();
   c->have_grid = gimg.ok;
   c->gblob_bytes = 0;
   if (gimg.ok) {
-    if ((rc = upload(c->gblob, gimg.blob))) return rc;
-    c->gblob_bytes = (uint32_t)gimg.blob.size();
+    if (!grid_on_device && (rc = upload(c->gblob, gimg.blob))) return rc;
+    c->gblob_bytes = (uint32_t)(grid_on_device ? gimg.total_bytes : gimg.blob.size());
   }
   for (auto &o : c->occ) o[0] = o[1] = o[2] = 0;
 
@@ -471,8 +528,10 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     d32.gblob_bytes = 0;
     if (gimg.ok) {
       Image32 g32;
-      make_image32(gimg.blob.data(), gimg.off_sph, sph, mov, tri, pmat, mats_bytes, g32);
+      make_image32(grid_on_device ? nullptr : gimg.blob.data(), gimg.off_sph, sph, mov, tri, pmat, mats_bytes, g32);
       if ((rc = upload(c->gblob32, g32.blob))) return rc;
+      if (grid_on_device)  // header, cells and ids exist only in HBM
+        HIPCHK(hipMemcpy(c->gblob32.p, c->gblob.p, gimg.off_sph, hipMemcpyDeviceToDevice));
       d32.gblob = (const unsigned char *)c->gblob32.p;
       d32.gblob_bytes = (uint32_t)g32.blob.size();
       d32.g_off_sph = g32.off_sph;
@@ -733,6 +792,29 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
       stats->node_tests = c->h_counters[3];
     }
   }
+  return RTOW_OK;
+}
+
+// Diagnostic: copy a resident scene image to the host (0 BVH, 1 grid, 2 BVH of the f32 build,
+// 3 grid of the f32 build).  Used by the tests to compare host- and device-built images.
+int rtow_debug_image(rtow_ctx *c, int32_t which, void *out, int64_t capacity, int64_t *size_out) {
+  if (!c || !size_out) return fail(RTOW_EINVAL, "NULL argument");
+  if (!c->have_scene) return fail(RTOW_ENOSCENE, "no scene uploaded");
+  const void *src = nullptr;
+  int64_t bytes = 0;
+  switch (which) {
+    case 0: src = c->blob.p; bytes = c->ds.blob_bytes; break;
+    case 1: src = c->gblob.p; bytes = c->ds.gblob_bytes; break;
+    case 2: src = c->blob32.p; bytes = c->ds32.blob_bytes; break;
+    case 3: src = c->gblob32.p; bytes = c->ds32.gblob_bytes; break;
+    default: return fail(RTOW_EINVAL, "unknown image %d", which);
+  }
+  *size_out = bytes;
+  if (!out) return RTOW_OK;  // size query
+  if (capacity < bytes) return fail(RTOW_EINVAL, "buffer too small (%lld < %lld)", (long long)capacity, (long long)bytes);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (bytes) HIPCHK(hipMemcpy(out, src, (size_t)bytes, hipMemcpyDeviceToHost));
   return RTOW_OK;
 }
 

@@ -30,6 +30,7 @@ struct GridImage {
   uint32_t off_pmat = 0, off_mats = 0;  // material index per primitive, material records
   int32_t n[3] = {1, 1, 1};
   uint32_t n_large = 0;
+  size_t total_bytes = 0;
   bool ok = false;  // false: scene not suited (e.g. lists too long) — use the BVH
 };
 
@@ -38,6 +39,75 @@ struct B3 {
   double mn[3], mx[3];
 };
 }  // namespace grid_detail
+
+// Grid origin, resolution and cell size from the bounds of the small primitives — shared by the
+// host builder below and the device builder (rtow_build_grid.hip), so both lay out the same grid.
+// `scale_prims`: max |coordinate| over the small bounds (unpadded) and the large primitives' bounds.
+struct GridHeader {
+  double pad = 0.0;
+  int32_t n[3] = {1, 1, 1};
+  float gminf[3] = {0, 0, 0}, cellf[3] = {1, 1, 1}, invf[3] = {1, 1, 1};
+};
+inline void grid_header(const double gmn_in[3], const double gmx_in[3], double scale_prims, const double cam_origin[3],
+                        size_t n_small, double cells_per_prim, GridHeader &h) {
+  // the f32 DDA sees the ray rounded to f32: pad by more than that rounding can move the ray
+  // or a cell boundary anywhere in the scene (same reasoning as the BVH boxes, rtow_bvh.h)
+  double scale = std::max(1.0, scale_prims);
+  for (int k = 0; k < 3; ++k) scale = std::max(scale, std::fabs(cam_origin[k]));
+  h.pad = 4e-6 * scale;
+  double gmn[3], gmx[3], ext[3];
+  for (int k = 0; k < 3; ++k) {
+    gmn[k] = gmn_in[k] - 2 * h.pad;
+    gmx[k] = gmx_in[k] + 2 * h.pad;
+    ext[k] = std::max(gmx[k] - gmn[k], 1e-9);
+  }
+  const double target = std::min(std::max(cells_per_prim * (double)n_small, 8.0), 32768.0);
+  const double s = std::cbrt(ext[0] * ext[1] * ext[2] / target);
+  for (int k = 0; k < 3; ++k) {
+    int nk = (int)std::ceil(ext[k] / s);
+    nk = std::min(std::max(nk, 1), 128);
+    h.n[k] = nk;
+    h.gminf[k] = std::nextafterf((float)gmn[k], -INFINITY);
+    // cell size as f32, rounded up so n*cell covers the extent
+    h.cellf[k] = std::nextafterf((float)((gmx[k] - (double)h.gminf[k]) / nk), INFINITY);
+    h.invf[k] = 1.0f / h.cellf[k];
+  }
+}
+
+// Section offsets and everything but the header, the cell words and the id section.
+inline void layout_grid_image(size_t ncell, size_t total_ids, size_t n_large, const std::vector<double> &sph,
+                              const std::vector<double> &mov, const std::vector<double> &tri,
+                              const std::vector<int32_t> &prim_mat, const std::vector<unsigned char> &mats_bytes,
+                              GridImage &img, bool offsets_only = false) {
+  const size_t hdr = 64;
+  img.off_cells = (uint32_t)hdr;
+  const size_t cells_bytes = ((ncell * 4 + 15) / 16) * 16;
+  img.off_ids = (uint32_t)(hdr + cells_bytes);
+  const size_t ids_bytes = ((total_ids * 4 + 15) / 16) * 16;
+  img.off_sph = (uint32_t)(img.off_ids + ids_bytes);
+  img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
+  img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
+  img.off_pmat = (uint32_t)((((size_t)img.off_tri + tri.size() * 8) + 15) / 16 * 16);
+  img.off_mats = (uint32_t)((((size_t)img.off_pmat + prim_mat.size() * 4) + 15) / 16 * 16);
+  const size_t total = (size_t)img.off_mats + mats_bytes.size();
+  img.total_bytes = ((total + 15) / 16) * 16;
+  img.n_large = (uint32_t)n_large;
+  if (offsets_only) return;
+  img.blob.assign(img.total_bytes, 0);
+  if (!prim_mat.empty()) std::memcpy(img.blob.data() + img.off_pmat, prim_mat.data(), prim_mat.size() * 4);
+  if (!mats_bytes.empty()) std::memcpy(img.blob.data() + img.off_mats, mats_bytes.data(), mats_bytes.size());
+}
+
+// the 64-byte image header (see the layout comment at the top)
+inline void write_grid_header(unsigned char *h, const GridHeader &hd, uint32_t n_large, uint32_t off_large) {
+  std::memset(h, 0, 64);
+  std::memcpy(h + 0, hd.gminf, 12);
+  std::memcpy(h + 12, hd.cellf, 12);
+  std::memcpy(h + 24, hd.invf, 12);
+  std::memcpy(h + 36, hd.n, 12);
+  std::memcpy(h + 48, &n_large, 4);
+  std::memcpy(h + 52, &off_large, 4);
+}
 
 // sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
 inline void build_grid_image(const std::vector<double> &sph, const std::vector<double> &sph_r,
@@ -101,34 +171,21 @@ inline void build_grid_image(const std::vector<double> &sph, const std::vector<d
       gmn[k] = std::min(gmn[k], pb[i].mn[k]);
       gmx[k] = std::max(gmx[k], pb[i].mx[k]);
     }
-  // the f32 DDA sees the ray rounded to f32: pad by more than that rounding can move the ray
-  // or a cell boundary anywhere in the scene (same reasoning as the BVH boxes, rtow_bvh.h)
   double scale = 1.0;
   for (int k = 0; k < 3; ++k) {
     scale = std::max(scale, std::max(std::fabs(gmn[k]), std::fabs(gmx[k])));
-    scale = std::max(scale, std::fabs(cam_origin[k]));
     for (int i : large) scale = std::max(scale, std::max(std::fabs(pb[i].mn[k]), std::fabs(pb[i].mx[k])));
   }
-  const double pad = 4e-6 * scale;
-  double ext[3];
-  for (int k = 0; k < 3; ++k) {
-    gmn[k] -= 2 * pad;
-    gmx[k] += 2 * pad;
-    ext[k] = std::max(gmx[k] - gmn[k], 1e-9);
-  }
-  const double target = std::min(std::max(cells_per_prim * (double)small.size(), 8.0), 32768.0);
-  const double s = std::cbrt(ext[0] * ext[1] * ext[2] / target);
+  GridHeader hd;
+  grid_header(gmn, gmx, scale, cam_origin, small.size(), cells_per_prim, hd);
+  const double pad = hd.pad;
   long long ncell = 1;
-  float cellf[3], gminf[3], invf[3];
+  float cellf[3], gminf[3];
   for (int k = 0; k < 3; ++k) {
-    int nk = (int)std::ceil(ext[k] / s);
-    nk = std::min(std::max(nk, 1), 128);
-    img.n[k] = nk;
-    ncell *= nk;
-    gminf[k] = std::nextafterf((float)gmn[k], -INFINITY);
-    // cell size as f32, rounded up so n*cell covers the extent
-    cellf[k] = std::nextafterf((float)((gmx[k] - (double)gminf[k]) / nk), INFINITY);
-    invf[k] = 1.0f / cellf[k];
+    img.n[k] = hd.n[k];
+    ncell *= hd.n[k];
+    gminf[k] = hd.gminf[k];
+    cellf[k] = hd.cellf[k];
   }
   // register every small primitive in all cells its padded bounds touch (computed with the
   // same f32 gmin/cell the kernel uses, widened by one ulp-ish margin through `pad`)
@@ -153,21 +210,7 @@ inline void build_grid_image(const std::vector<double> &sph, const std::vector<d
   }
   if (total_ids >= (1u << 24)) return;
 
-  const size_t hdr = 64;
-  img.off_cells = (uint32_t)hdr;
-  const size_t cells_bytes = (((size_t)ncell * 4 + 15) / 16) * 16;
-  img.off_ids = (uint32_t)(hdr + cells_bytes);
-  const size_t ids_bytes = ((total_ids * 4 + 15) / 16) * 16;
-  img.off_sph = (uint32_t)(img.off_ids + ids_bytes);
-  img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
-  img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
-  img.off_pmat = (uint32_t)((((size_t)img.off_tri + tri.size() * 8) + 15) / 16 * 16);
-  img.off_mats = (uint32_t)((((size_t)img.off_pmat + prim_mat.size() * 4) + 15) / 16 * 16);
-  const size_t total = (size_t)img.off_mats + mats_bytes.size();
-  img.blob.assign(((total + 15) / 16) * 16, 0);
-  if (!prim_mat.empty()) std::memcpy(img.blob.data() + img.off_pmat, prim_mat.data(), prim_mat.size() * 4);
-  if (!mats_bytes.empty()) std::memcpy(img.blob.data() + img.off_mats, mats_bytes.data(), mats_bytes.size());
-  img.n_large = (uint32_t)large.size();
+  layout_grid_image((size_t)ncell, total_ids, large.size(), sph, mov, tri, prim_mat, mats_bytes, img);
 
   std::vector<int32_t> ids;
   ids.reserve(total_ids);
@@ -181,12 +224,7 @@ inline void build_grid_image(const std::vector<double> &sph, const std::vector<d
   ids.insert(ids.end(), large.begin(), large.end());
 
   unsigned char *h = img.blob.data();
-  std::memcpy(h + 0, gminf, 12);
-  std::memcpy(h + 12, cellf, 12);
-  std::memcpy(h + 24, invf, 12);
-  std::memcpy(h + 36, img.n, 12);
-  std::memcpy(h + 48, &img.n_large, 4);
-  std::memcpy(h + 52, &off_large, 4);
+  write_grid_header(h, hd, img.n_large, off_large);
   std::memcpy(h + img.off_cells, cells.data(), cells.size() * 4);
   if (!ids.empty()) std::memcpy(h + img.off_ids, ids.data(), ids.size() * 4);
   if (!sph.empty()) std::memcpy(h + img.off_sph, sph.data(), sph.size() * 8);

@@ -99,7 +99,7 @@ EXPORTS = [
     "rtow_render", "rtow_host_scene_cover", "rtow_host_scene_obj", "rtow_host_scene_free",
     "rtow_host_rng_reset", "rtow_host_ppm", "rtow_host_free", "rtow_tonemap_device",
     "rtow_profile_collect", "rtow_debug_counters", "rtow_render_rgb8",
-    "rtow_ctx_set_builder", "rtow_build_info",
+    "rtow_ctx_set_builder", "rtow_build_info", "rtow_debug_image",
 ]
 
 
@@ -144,6 +144,7 @@ def lib():
     L.rtow_tonemap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.rtow_ctx_set_builder.argtypes = [C.c_void_p, C.c_int32]
     L.rtow_build_info.argtypes = [C.c_void_p, C.POINTER(BuildInfo)]
+    L.rtow_debug_image.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     if L.rtow_abi_version() != RTOW_ABI_VERSION:
         raise RtowError("librtow.so ABI version mismatch")
     _lib = L
@@ -260,6 +261,14 @@ class Context:
     def set_builder(self, builder: int):
         """BUILDER_HOST_SAH (default) or BUILDER_DEVICE_LBVH; applies from the next upload."""
         check(lib().rtow_ctx_set_builder(self._h, builder), "rtow_ctx_set_builder")
+
+    def debug_image(self, which: int) -> bytes:
+        """A resident scene image (0 BVH, 1 grid, 2/3 the f32 build's), for tests."""
+        n = C.c_int64()
+        check(lib().rtow_debug_image(self._h, which, None, 0, C.byref(n)), "rtow_debug_image")
+        buf = (C.c_ubyte * max(n.value, 1))()
+        check(lib().rtow_debug_image(self._h, which, buf, n.value, C.byref(n)), "rtow_debug_image")
+        return bytes(buf[:n.value])
 
     def build_info(self) -> BuildInfo:
         bi = BuildInfo()

@@ -155,3 +155,58 @@ def test_set_builder_rejects_unknown_values(ctx):
     with pytest.raises(rtow.RtowError):
         ctx.set_builder(7)
     ctx.set_builder(rtow.BUILDER_HOST_SAH)
+
+
+# ---- the grid image, built on the device (csrc/rtow_build_grid.hip) -------------------------------
+@pytest.mark.parametrize("moving", [False, True])
+def test_device_built_grid_image_is_byte_identical(ctx, dctx, moving):
+    """Same arithmetic on both sides (bounds, median split, grid_header(), cell ranges), lists in
+    ascending id order: the device-built grid image equals the host-built one byte for byte —
+    also the f32 build's image derived from it."""
+    scene = rtow.HostScene.cover(11, 1.5, moving)
+    ctx.set_builder(rtow.BUILDER_HOST_SAH)
+    ctx.upload(scene)
+    dctx.upload(scene)
+    for which in (1, 3):
+        a, b = ctx.debug_image(which), dctx.debug_image(which)
+        assert len(a) == len(b) and len(a) > 1000
+        assert a == b, f"image {which}: first difference at byte {next(i for i in range(len(a)) if a[i] != b[i])}"
+
+
+def test_device_built_grid_other_scenes(ctx, dctx):
+    import ctypes as C
+
+    cases = [rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9), rtow.HostScene.cover(3, 1.5, True)]
+    sc, keep = _random_sphere_scene(hollow=True)
+    cases.append(sc)
+    for scene in cases:
+        ctx.set_builder(rtow.BUILDER_HOST_SAH)
+        ctx.upload(scene)
+        dctx.upload(scene)
+        assert ctx.debug_image(1) == dctx.debug_image(1)
+
+
+def test_device_built_grid_strict_render_is_bit_identical_to_oracle(dctx):
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    cfg = rtow.make_config(120, 80, 4, 2, 50, seed=1, precision=rtow.F64_STRICT, kernel=rtow.KERNEL_GRID)
+    img, st = dctx.render(scene, cfg)
+    assert st.kernel_used == rtow.KERNEL_GRID
+    ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+    assert st.segments == ost.segments and np.array_equal(img, ref)
+
+
+def test_device_grid_build_falls_back_like_the_host(ctx, dctx):
+    """A scene the grid does not suit (one primitive: no 'small' set after the median split is
+    fine, but 70 equal spheres at one point exceed nothing; many large ones do): both builders
+    must agree on whether there is a grid at all."""
+    keep = []
+    rng = np.random.default_rng(1)
+    geom = np.zeros((80, 4))
+    geom[:, :3] = rng.uniform(-3, 3, size=(80, 3))
+    geom[:10, 3] = 0.01          # ten tiny spheres ...
+    geom[10:, 3] = 1.5           # ... and seventy huge ones: more than 64 'large' primitives
+    sc = _sphere_scene(geom, keep)
+    ctx.set_builder(rtow.BUILDER_HOST_SAH)
+    ctx.upload(sc)
+    dctx.upload(sc)
+    assert ctx.build_info().grid_image_bytes == dctx.build_info().grid_image_bytes
