@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <string>
@@ -635,6 +636,45 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   const unsigned long long npix = (unsigned long long)rows * cfg->image_width;
   const int streams_now = cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams;
   const unsigned long long n_items = npix * (unsigned long long)streams_now;
+  // Large sample counts: the per-stream partial sums (24 B per pixel and stream) are bounded by
+  // tracing the streams in ranges that accumulate onto d_rgb_sums — bit-identical to one launch
+  // (the reduce kernel adds stream sums in stream order either way).
+  {
+    unsigned long long cap_bytes = 8ull << 30;
+    if (const char *e = std::getenv("RTOW_PARTIALS_MAX_MB")) cap_bytes = (unsigned long long)std::atoll(e) << 20;
+    const unsigned long long per_stream = npix * 24ull;
+    unsigned long long max_streams = per_stream ? cap_bytes / per_stream : (unsigned long long)streams_now;
+    if (per_stream && 0xfffffff0ULL / npix < max_streams) max_streams = 0xfffffff0ULL / npix;  // 32-bit item index
+    if (max_streams < 1) max_streams = 1;
+    if ((unsigned long long)streams_now > max_streams && spt > 0 && npix > 0) {
+      rtow_stats_t total;
+      std::memset(&total, 0, sizeof total);
+      const int first0 = cfg->stream_count > 0 ? cfg->stream_first : 0;
+      for (int done = 0; done < streams_now;) {
+        const int now = (int)std::min<unsigned long long>(max_streams, (unsigned long long)(streams_now - done));
+        rtow_config_t part = *cfg;
+        part.stream_first = first0 + done;
+        part.stream_count = now;
+        part.accumulate = (done > 0 || cfg->accumulate) ? 1 : 0;
+        rtow_stats_t st1;
+        rc = rtow_render_device(c, &part, d_rgb_sums, hip_stream, stats ? &st1 : nullptr);
+        if (rc) return rc;
+        if (stats) {
+          total.samples += st1.samples;
+          total.segments += st1.segments;
+          total.prim_tests += st1.prim_tests;
+          total.node_tests += st1.node_tests;
+          total.kernel_ms += st1.kernel_ms;
+          total.total_ms += st1.total_ms;
+          total.local_rows = st1.local_rows;
+          total.kernel_used = st1.kernel_used;
+        }
+        done += now;
+      }
+      if (stats) *stats = total;
+      return RTOW_OK;
+    }
+  }
   if (n_items > 0xfffffff0ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
 
   int kernel = cfg->kernel;

@@ -456,3 +456,17 @@ def test_full_size_cover_properties(ctx):
     part, pst = ctx.render(scene, part_cfg)
     rows = rtow.local_rows(part_cfg)
     assert len(rows) == 104 and np.array_equal(part, img[rows])
+
+
+def test_stream_ranges_are_chunked_automatically_and_bit_identical(ctx, monkeypatch):
+    """Large sample counts: the per-stream partial sums are bounded by tracing the streams in
+    ranges (RTOW_PARTIALS_MAX_MB, default 8 GiB); the image is the one-launch image bit for bit."""
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    cfg = rtow.make_config(120, 80, 24, 12, 50, seed=2, precision=rtow.F64_STRICT)
+    whole, sw = ctx.render(scene, cfg)
+    monkeypatch.setenv("RTOW_PARTIALS_MAX_MB", "1")  # 120*80*24 B = 230 kB per stream -> 4 streams per launch
+    parts, sp = ctx.render(scene, cfg)
+    assert np.array_equal(whole, parts)
+    assert sp.samples == sw.samples and sp.segments == sw.segments
+    ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+    assert np.array_equal(parts, ref)
