@@ -4,6 +4,7 @@ the PPM writer matches, row partitioning, argument validation, the CLI."""
 import ctypes as C
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -134,3 +135,21 @@ def test_general_obj_loads_all_shapes_and_triangulates(tmp_path, monkeypatch):
     assert np.array_equal(tri[0], [-1, -1, 0, 1, -1, 0, 1, 1, 0])      # fan: (v0, v1, v2)
     assert np.array_equal(tri[1], [-1, -1, 0, 1, 1, 0, -1, 1, 0])      #      (v0, v2, v3)
     assert np.array_equal(tri[2], [-1, -1, -1, 1, -1, -1, 0, 1, -1])   # second shape, relative indices
+
+
+def test_product_path_fails_loudly_without_a_hip_device():
+    """No CPU fallback: on a machine without a GPU every device entry point reports RTOW_ENODEV /
+    RTOW_EHIP instead of rendering on the host (the oracle is test infrastructure only)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    with pytest.raises(rtow.RtowError) as ei:
+        rtow.Context(0)
+    assert "HIP" in str(ei.value) or "device" in str(ei.value)
+    exe = REPO / "raytracing-one-weekend_amd" / "rtweekend"
+    r = subprocess.run([str(exe), "-w", "16", "-s", "4", "-t", "1", "-n", "0"], capture_output=True)
+    assert r.returncode != 0 and not r.stdout.startswith(b"P3")
+    # bench.py refuses too
+    b = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True)
+    assert b.returncode != 0 and b"no CPU fallback" in b.stderr + b.stdout
