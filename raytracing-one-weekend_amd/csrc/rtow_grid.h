@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -43,6 +44,15 @@ struct B3 {
 // Grid origin, resolution and cell size from the bounds of the small primitives — shared by the
 // host builder below and the device builder (rtow_build_grid.hip), so both lay out the same grid.
 // `scale_prims`: max |coordinate| over the small bounds (unpadded) and the large primitives' bounds.
+// An axis whose extent is below this many cell sizes gets a single layer of cells instead of two
+// thin ones (the slab of small spheres with moving spheres swept 0.5 upwards: 3.2 instead of 3.7 cell
+// steps per segment, +1.6 %; no effect on the static scene).  RTOW_GRID_FLAT overrides; 1.0 = plain
+// rounding up.
+inline double grid_flat_ratio() {
+  const char *e = std::getenv("RTOW_GRID_FLAT");
+  return e ? std::atof(e) : 1.5;
+}
+
 struct GridHeader {
   double pad = 0.0;
   int32_t n[3] = {1, 1, 1};
@@ -63,8 +73,10 @@ inline void grid_header(const double gmn_in[3], const double gmx_in[3], double s
   }
   const double target = std::min(std::max(cells_per_prim * (double)n_small, 8.0), 32768.0);
   const double s = std::cbrt(ext[0] * ext[1] * ext[2] / target);
+  const double flat_ratio = grid_flat_ratio();
   for (int k = 0; k < 3; ++k) {
     int nk = (int)std::ceil(ext[k] / s);
+    if (ext[k] < flat_ratio * s) nk = 1;  // a thin slab: one layer (see grid_flat_ratio())
     nk = std::min(std::max(nk, 1), 128);
     h.n[k] = nk;
     h.gminf[k] = std::nextafterf((float)gmn[k], -INFINITY);
