@@ -33,7 +33,8 @@ static void usage(const char *argv0) {
                "  --kernel auto|brute|bvh|grid  closest-hit strategy (default auto)\n"
                "  --builder host|device       BVH build: host SAH (default) or on the GPU (LBVH)\n"
                "  --p6                        binary P6 output, write_color on the device\n"
-               "  --general-obj               with -l: load every shape and fan-triangulate polygons\n";
+               "  --general-obj               with -l: load every shape and fan-triangulate polygons\n"
+               "  --gpus INT                  tile-split over INT devices (--device is the first)\n";
 }
 
 int main(int argc, char *argv[]) {
@@ -88,6 +89,11 @@ int main(int argc, char *argv[]) {
         opt.binary_ppm = true;
       } else if (std::strcmp(a, "--general-obj") == 0) {
         opt.general_obj = true;
+      } else if (std::strcmp(a, "--gpus") == 0) {
+        opt.gpus = std::stoi(value());
+        if (opt.gpus < 1 || opt.gpus > 64) throw std::runtime_error("--gpus: 1..64");
+      } else if (std::strcmp(a, "--gpus-same-device") == 0) {  // test hook: every rank on --device
+        opt.gpus_same_device = true;
       } else if (std::strcmp(a, "--builder") == 0) {
         const std::string v = value();
         if (v == "host") opt.builder = 0;

@@ -2,6 +2,7 @@
 // call into the HIP path through the C-ABI, and the reference's PPM writer.
 #include "render.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -9,6 +10,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -198,7 +200,7 @@ void render(const Scene &world, const Config &cfg) {
   namespace khr = std::chrono;
   const DeviceOptions &opt = device_options();
   std::cerr << "Started rendering with " << cfg.nthreads << " sample streams on HIP device "
-            << opt.device << "\n";
+            << opt.device << (opt.gpus > 1 ? " (+" + std::to_string(opt.gpus - 1) + " more)" : std::string()) << "\n";
   khr::time_point start{khr::high_resolution_clock::now()};
 
   FlatScene *flat = flatten(world);
@@ -219,20 +221,66 @@ void render(const Scene &world, const Config &cfg) {
   const size_t nvalues = (size_t)cfg.image_width * (image_height > 0 ? image_height : 0) * 3;
   std::vector<double> image(opt.binary_ppm ? 0 : nvalues);
   std::vector<unsigned char> rgb8(opt.binary_ppm ? nvalues : 0);
-  rtow_ctx *ctx = nullptr;
   rtow_stats_t st;
-  int err = rtow_ctx_create(opt.device, &ctx);
-  if (err == RTOW_OK && opt.builder >= 0) err = rtow_ctx_set_builder(ctx, opt.builder);
+  std::memset(&st, 0, sizeof st);
   rtow_build_info_t bi;
   std::memset(&bi, 0, sizeof bi);
-  if (err == RTOW_OK)
-    err = opt.binary_ppm ? rtow_render_rgb8(ctx, flat_view(flat), &rc, rgb8.data(), &st)
-                         : rtow_render(ctx, flat_view(flat), &rc, image.data(), &st);
-  std::string msg = err == RTOW_OK ? "" : rtow_last_error();
-  if (err == RTOW_OK) (void)rtow_build_info(ctx, &bi);
-  rtow_ctx_destroy(ctx);
+  const int ngpus = std::max(opt.gpus, 1);
+  std::vector<int> errs(ngpus, RTOW_OK);
+  std::vector<std::string> msgs(ngpus);
+  std::vector<rtow_stats_t> stats(ngpus);
+  std::vector<rtow_build_info_t> infos(ngpus);
+  // one rank = one device = one host thread; rank r owns the strips r, r+N, r+2N, ...
+  auto run_rank = [&](int rank) {
+    rtow_config_t mine = rc;
+    mine.rank = rank;
+    mine.nranks = ngpus;
+    rtow_ctx *ctx = nullptr;
+    int err = rtow_ctx_create(opt.gpus_same_device ? opt.device : opt.device + rank, &ctx);
+    if (err == RTOW_OK && opt.builder >= 0) err = rtow_ctx_set_builder(ctx, opt.builder);
+    const int rows = rtow_local_rows(&mine);
+    std::vector<int32_t> row_ids((size_t)std::max(rows, 0));
+    if (err == RTOW_OK && rows > 0) (void)rtow_local_row_list(&mine, row_ids.data(), rows);
+    const size_t row_values = (size_t)cfg.image_width * 3;
+    std::vector<double> part(opt.binary_ppm ? 0 : row_values * (size_t)std::max(rows, 0));
+    std::vector<unsigned char> part8(opt.binary_ppm ? row_values * (size_t)std::max(rows, 0) : 0);
+    std::memset(&stats[rank], 0, sizeof(rtow_stats_t));
+    if (err == RTOW_OK)
+      err = opt.binary_ppm ? rtow_render_rgb8(ctx, flat_view(flat), &mine, part8.data(), &stats[rank])
+                           : rtow_render(ctx, flat_view(flat), &mine, part.data(), &stats[rank]);
+    if (err == RTOW_OK) {
+      (void)rtow_build_info(ctx, &infos[rank]);
+      for (int i = 0; i < rows; ++i) {  // this rank's rows, ascending, into their global places
+        if (opt.binary_ppm)
+          std::memcpy(rgb8.data() + (size_t)row_ids[i] * row_values, part8.data() + (size_t)i * row_values, row_values);
+        else
+          std::memcpy(image.data() + (size_t)row_ids[i] * row_values, part.data() + (size_t)i * row_values,
+                      row_values * sizeof(double));
+      }
+    } else {
+      msgs[rank] = rtow_last_error();  // thread-local text of this rank's failure
+    }
+    errs[rank] = err;
+    rtow_ctx_destroy(ctx);
+  };
+  if (ngpus == 1) {
+    run_rank(0);
+  } else {
+    std::vector<std::thread> workers;
+    for (int r = 0; r < ngpus; ++r) workers.emplace_back(run_rank, r);
+    for (auto &w : workers) w.join();
+  }
   flat_free(flat);
-  if (err != RTOW_OK) throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + msg);
+  for (int r = 0; r < ngpus; ++r)
+    if (errs[r] != RTOW_OK)
+      throw std::runtime_error("HIP render failed on rank " + std::to_string(r) + " (" + std::to_string(errs[r]) +
+                               "): " + msgs[r]);
+  bi = infos[0];
+  for (int r = 0; r < ngpus; ++r) {
+    st.samples += stats[r].samples;
+    st.segments += stats[r].segments;
+    st.kernel_ms = std::max(st.kernel_ms, stats[r].kernel_ms);
+  }
 
   const int spp_eff = cfg.samples_per_pixel / cfg.nthreads * cfg.nthreads;  // src/render.cpp:185
   if (opt.binary_ppm) {

@@ -470,3 +470,25 @@ def test_stream_ranges_are_chunked_automatically_and_bit_identical(ctx, monkeypa
     assert sp.samples == sw.samples and sp.segments == sw.segments
     ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
     assert np.array_equal(parts, ref)
+
+
+def test_rtweekend_gpus_flag_partitions_like_one_device(ctx):
+    """rtweekend --gpus N: one host thread and context per device, strips scattered into the host
+    image.  With every rank on device 0 (test hook) the PPM must be the single-device PPM byte for
+    byte, P3 and P6."""
+    import subprocess
+
+    from conftest import REPO
+
+    exe = REPO / "raytracing-one-weekend_amd" / "rtweekend"
+    base = [str(exe), "-w", "96", "-a", "1.5", "-s", "8", "-c", "20", "-t", "2", "--precision", "strict"]
+    one = subprocess.run(base, capture_output=True, check=True)
+    for n in ("2", "3"):
+        many = subprocess.run(base + ["--gpus", n, "--gpus-same-device"], capture_output=True, check=True)
+        assert many.stdout == one.stdout
+    p6a = subprocess.run(base + ["--p6"], capture_output=True, check=True)
+    p6b = subprocess.run(base + ["--p6", "--gpus", "4", "--gpus-same-device"], capture_output=True, check=True)
+    assert p6a.stdout == p6b.stdout and p6a.stdout.startswith(b"P6")
+    # a device index that does not exist is an error, not a silent fallback
+    bad = subprocess.run(base + ["--gpus", "64"], capture_output=True)
+    assert bad.returncode != 0
