@@ -182,12 +182,15 @@ struct PhiloxDraw {
   double buf[3];
   int have = 0, pos = 0;
   double stash_time = 0.0;   // third value of the jitter request
+  double stash_disk[2] = {0.0, 0.0};  // lens-disk candidate waiting in a block already drawn
+  int disk_k = 0;            // lens-disk candidates handed out in this sample
   bool coin_peeked = false;  // the next scatter request re-uses the block the coin came from
   void begin_sample(uint32_t p, uint32_t s) {
     pixel = p;
     sample = s;
     r = 0;
     have = pos = 0;
+    disk_k = 0;
     coin_peeked = false;
   }
   void block(uint32_t req, uint32_t o[4]) const {
@@ -195,21 +198,38 @@ struct PhiloxDraw {
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     philox4x32(ctr, key, o, kPhiloxRounds);
   }
+  // The first block of a sample: pixel jitter and shutter time, 21 bits each (the top bits of words
+  // 0..2), and the FIRST lens-disk candidate, 32 bits per coordinate (word 3 and the 11+11+10 low
+  // bits left in words 0..2).
   void request_jitter() {
     uint32_t o[4];
     block(r++, o);
-    const double s42 = 0x1p-42;
-    buf[0] = ((double)o[0] + (double)(o[3] & 1023u) * 4294967296.0) * s42;
-    buf[1] = ((double)o[1] + (double)((o[3] >> 10) & 1023u) * 4294967296.0) * s42;
-    stash_time = ((double)o[2] + (double)((o[3] >> 20) & 1023u) * 4294967296.0) * s42;
+    const double s21 = 0x1p-21, s32 = 0x1p-32;
+    buf[0] = (double)(o[0] >> 11) * s21;
+    buf[1] = (double)(o[1] >> 11) * s21;
+    stash_time = (double)(o[2] >> 11) * s21;
+    stash_disk[0] = (double)o[3] * s32;
+    stash_disk[1] = (double)((o[0] & 0x7ffu) | ((o[1] & 0x7ffu) << 11) | ((o[2] & 0x3ffu) << 22)) * s32;
+    disk_k = 0;
     have = 2;
     pos = 0;
   }
+  // Lens-disk candidates (two values each, 32 bits per value): #1 came with the jitter block; every
+  // further block carries two candidates, (w0, w1) and (w2, w3).
   void request_disk() {
-    uint32_t o[4];
-    block(r++, o);
-    buf[0] = canonical_from_words(o[0], o[1]);
-    buf[1] = canonical_from_words(o[2], o[3]);
+    if (disk_k == 0 || (disk_k & 1) == 0) {  // #1, or the second candidate of a block
+      buf[0] = stash_disk[0];
+      buf[1] = stash_disk[1];
+    } else {
+      uint32_t o[4];
+      block(r++, o);
+      const double s32 = 0x1p-32;
+      buf[0] = (double)o[0] * s32;
+      buf[1] = (double)o[1] * s32;
+      stash_disk[0] = (double)o[2] * s32;
+      stash_disk[1] = (double)o[3] * s32;
+    }
+    ++disk_k;
     have = 2;
     pos = 0;
   }
@@ -847,13 +867,15 @@ double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32
   g.seed = seed;
   g.begin_sample(pixel, sample);
   g.r = request;
-  if (kind == 0) {
+  if (kind == 0) {  // k = 0, 1: jitter; 2: time; 3, 4: the first lens-disk candidate
     g.request_jitter();
+    if (k >= 3) return g.stash_disk[k - 3];
     return k == 2 ? g.stash_time : g.buf[k];
   }
-  if (kind == 1) {
+  if (kind == 1) {  // a later lens-disk block: k = 0, 1 first candidate; 2, 3 second candidate
+    g.disk_k = 1;
     g.request_disk();
-    return g.buf[k];
+    return k < 2 ? g.buf[k] : g.stash_disk[k - 2];
   }
   if (k == 3) {
     g.request_coin();

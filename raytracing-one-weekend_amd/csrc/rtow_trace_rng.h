@@ -34,49 +34,31 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
   o3 = c3;
 }
 
-// (w0 + w1*2^32) / 2^64 with double rounding steps, < 1 enforced
-__device__ __forceinline__ double canonical_from_words(uint32_t w0, uint32_t w1) {
-  double sum = (double)w0 + (double)w1 * 4294967296.0;
-  double r = sum * 0x1p-64;
-  if (r >= 1.0) r = 0x1.fffffffffffffp-1;
-  return r;
-}
-
 // One request = one block (w0..w3); see oracle/rtow_oracle.cpp, struct PhiloxDraw.
-// jitter + shutter time: 42 bits each (word k + 10 bits of word 3)
-__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, double &u,
-                                                  double &v, double &t) {
-  const double s42 = 0x1p-42;
-  u = ((double)o0 + (double)(o3 & 1023u) * 4294967296.0) * s42;
-  v = ((double)o1 + (double)((o3 >> 10) & 1023u) * 4294967296.0) * s42;
-  t = ((double)o2 + (double)((o3 >> 20) & 1023u) * 4294967296.0) * s42;
-}
-// binary32 build: the top 24 bits of the same 42-bit values (truncated, so < 1 and within one
-// binary32 ulp of the binary64 build's value: both builds sample the same lens/pixel positions)
-__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, float &u,
-                                                  float &v, float &t) {
-  u = (float)(((o3 & 1023u) << 14) | (o0 >> 18)) * 0x1p-24f;
-  v = (float)((((o3 >> 10) & 1023u) << 14) | (o1 >> 18)) * 0x1p-24f;
-  t = (float)((((o3 >> 20) & 1023u) << 14) | (o2 >> 18)) * 0x1p-24f;
-}
-__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, real &u, real &v, real &t) {
+// First block of a sample: pixel jitter + shutter time, 21 bits each (top bits of words 0..2), and
+// the first lens-disk candidate, 32 bits per coordinate (word 3; the 11+11+10 low bits of words 0..2).
+__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, real &u, real &v, real &t, real &da,
+                                           real &db) {
   uint32_t o0, o1, o2, o3;
   philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
-  jitter_from_block(o0, o1, o2, o3, u, v, t);
+  const real s21 = real(0x1p-21), s32 = real(0x1p-32);
+  u = (real)(o0 >> 11) * s21;
+  v = (real)(o1 >> 11) * s21;
+  t = (real)(o2 >> 11) * s21;
+  da = (real)o3 * s32;
+  db = (real)((o0 & 0x7ffu) | ((o1 & 0x7ffu) << 11) | ((o2 & 0x3ffu) << 22)) * s32;
 }
-// disk candidate: two doubles, each from two words like the reference's doubles
-__device__ __forceinline__ void rng_disk(Rng &g, uint32_t k0, uint32_t k1, real &a, real &b) {
+// a further lens-disk block: two candidates, (w0, w1) and (w2, w3), 32 bits per coordinate
+__device__ __forceinline__ void rng_disk2(Rng &g, uint32_t k0, uint32_t k1, real &a0, real &b0, real &a1, real &b1) {
   uint32_t o0, o1, o2, o3;
   philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
-#ifdef RTOW_REAL_F32
-  a = (float)o1 * 0x1p-32f;  // the high words of the two doubles
-  b = (float)o3 * 0x1p-32f;
-#else
-  a = canonical_from_words(o0, o1);
-  b = canonical_from_words(o2, o3);
-#endif
+  const real s32 = real(0x1p-32);
+  a0 = (real)o0 * s32;
+  b0 = (real)o1 * s32;
+  a1 = (real)o2 * s32;
+  b1 = (real)o3 * s32;
 }
 // unit-ball candidate (32 bits per coordinate); the spare word is the dielectric coin of
 // the bounce when this is its first candidate

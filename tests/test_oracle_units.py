@@ -54,13 +54,17 @@ def test_philox_requests():
     out = (C.c_uint32 * 4)()
     L.orc_philox4x32((C.c_uint32 * 4)(3, 7, 1000, 0), (C.c_uint32 * 2)(42, 0), out, R)
     w = list(out)
-    # disk: two doubles mapped like the reference maps two mt19937 words
-    assert L.orc_philox_request(42, 1000, 7, 3, 1, 0) == (w[0] + w[1] * 2.0**32) / 2.0**64
-    assert L.orc_philox_request(42, 1000, 7, 3, 1, 1) == (w[2] + w[3] * 2.0**32) / 2.0**64
-    # jitter + time: 42 bits each (word k + 10 bits of word 3)
+    # a lens-disk block after the first candidate: two candidates, 32 bits per coordinate
+    for k in range(4):
+        assert L.orc_philox_request(42, 1000, 7, 3, 1, k) == w[k] / 2.0**32
+    # first block of a sample: jitter + time, the top 21 bits of words 0..2 ...
     for k in range(3):
-        want = (w[k] + ((w[3] >> (10 * k)) & 1023) * 2.0**32) / 2.0**42
+        want = (w[k] >> 11) / 2.0**21
         assert L.orc_philox_request(42, 1000, 7, 3, 0, k) == want and want < 1.0
+    # ... and the first lens-disk candidate: word 3, and the 11+11+10 low bits left in words 0..2
+    assert L.orc_philox_request(42, 1000, 7, 3, 0, 3) == w[3] / 2.0**32
+    low = (w[0] & 0x7ff) | ((w[1] & 0x7ff) << 11) | ((w[2] & 0x3ff) << 22)
+    assert L.orc_philox_request(42, 1000, 7, 3, 0, 4) == low / 2.0**32
     # scatter candidate: 32 bits per coordinate, the coin in the spare word
     for k in range(4):
         assert L.orc_philox_request(42, 1000, 7, 3, 2, k) == w[k] / 2.0**32
