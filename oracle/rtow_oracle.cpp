@@ -139,6 +139,7 @@ struct MtGlobal {
   void request_time() {}
   void request_coin() {}
   void request_scatter() {}
+  void begin_scatter() {}
 };
 
 // Philox4x32-R (Salmon et al., SC'11).  The device path uses R = 7, the fastest member
@@ -184,6 +185,8 @@ struct PhiloxDraw {
   double stash_time = 0.0;   // third value of the jitter request
   double stash_disk[2] = {0.0, 0.0};  // lens-disk candidate waiting in a block already drawn
   int disk_k = 0;            // lens-disk candidates handed out in this sample
+  double stash_scat[3] = {0.0, 0.0, 0.0};  // unit-ball candidate waiting in a block already drawn
+  int scat_k = 0;            // unit-ball candidates handed out in this bounce
   bool coin_peeked = false;  // the next scatter request re-uses the block the coin came from
   void begin_sample(uint32_t p, uint32_t s) {
     pixel = p;
@@ -238,20 +241,41 @@ struct PhiloxDraw {
     have = 1;
     pos = 0;
   }
+  // Unit-ball candidates: 21 bits per coordinate, one candidate per pair of words — x and y are
+  // the top 21 bits of the two words, z the 11 + 10 low bits left over.  The first block of a
+  // bounce carries ONE candidate (words 0, 1) and the dielectric coin (word 2, 32 bits); every
+  // further block carries two candidates, (w0, w1) and (w2, w3).
+  static void ball_from_pair(uint32_t lo, uint32_t hi, double out[3]) {
+    const double s21 = 0x1p-21;
+    out[0] = (double)(lo >> 11) * s21;
+    out[1] = (double)(hi >> 11) * s21;
+    out[2] = (double)((lo & 0x7ffu) | ((hi & 0x3ffu) << 11)) * s21;
+  }
+  void begin_scatter() { scat_k = 0; }
   void request_coin() {  // peek at the block the first scatter candidate will use
     uint32_t o[4];
     block(r, o);
-    buf[0] = (double)o[3] * 0x1p-32;
+    buf[0] = (double)o[2] * 0x1p-32;
     have = 1;
     pos = 0;
     coin_peeked = true;
   }
   void request_scatter() {
-    uint32_t o[4];
-    block(r++, o);
-    buf[0] = (double)o[0] * 0x1p-32;
-    buf[1] = (double)o[1] * 0x1p-32;
-    buf[2] = (double)o[2] * 0x1p-32;
+    if (scat_k == 0) {
+      uint32_t o[4];
+      block(r++, o);
+      ball_from_pair(o[0], o[1], buf);
+    } else if (scat_k & 1) {
+      uint32_t o[4];
+      block(r++, o);
+      ball_from_pair(o[0], o[1], buf);
+      ball_from_pair(o[2], o[3], stash_scat);
+    } else {
+      buf[0] = stash_scat[0];
+      buf[1] = stash_scat[1];
+      buf[2] = stash_scat[2];
+    }
+    ++scat_k;
     have = 3;
     pos = 0;
     coin_peeked = false;
@@ -280,6 +304,7 @@ inline V3 random_vec3(R &rng, double lo = 0.0, double hi = 1.0) {
 // and "random_unit_vector" returns it WITHOUT normalising.
 template <class R>
 inline V3 random_in_unit_sphere(R &rng) {
+  rng.begin_scatter();
   for (;;) {
     rng.request_scatter();
     V3 v = random_vec3(rng);
@@ -877,12 +902,18 @@ double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32
     g.request_disk();
     return k < 2 ? g.buf[k] : g.stash_disk[k - 2];
   }
-  if (k == 3) {
-    g.request_coin();
-    return g.buf[0];
+  if (kind == 2) {  // first unit-ball block of a bounce: k = 0..2 candidate, 3 the coin
+    if (k == 3) {
+      g.request_coin();
+      return g.buf[0];
+    }
+    g.request_scatter();
+    return g.buf[k];
   }
+  // kind 3: a later unit-ball block: k = 0..2 first candidate, 3..5 second candidate
+  g.scat_k = 1;
   g.request_scatter();
-  return g.buf[k];
+  return k < 3 ? g.buf[k] : g.stash_scat[k - 3];
 }
 
 // lots_of_balls(), src/main.cpp:23-83.

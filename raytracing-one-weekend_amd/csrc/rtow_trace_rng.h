@@ -60,14 +60,24 @@ __device__ __forceinline__ void rng_disk2(Rng &g, uint32_t k0, uint32_t k1, real
   a1 = (real)o2 * s32;
   b1 = (real)o3 * s32;
 }
-// unit-ball candidate (32 bits per coordinate); the spare word is the dielectric coin of
-// the bounce when this is its first candidate
+// Unit-ball candidates: 21 bits per coordinate, one candidate per pair of words (x, y: the top 21
+// bits of the two words; z: the 11 + 10 low bits left over).  The first block of a bounce carries
+// one candidate (words 0, 1) and the dielectric coin (word 2, 32 bits); a further block carries two.
+__device__ __forceinline__ V3 ball_from_pair(uint32_t lo, uint32_t hi) {
+  const real s21 = real(0x1p-21);
+  return V3{(real)(lo >> 11) * s21, (real)(hi >> 11) * s21, (real)((lo & 0x7ffu) | ((hi & 0x3ffu) << 11)) * s21};
+}
 __device__ __forceinline__ V3 rng_scatter(Rng &g, uint32_t k0, uint32_t k1, real &coin) {
   uint32_t o0, o1, o2, o3;
   philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
-  const real s32 = real(0x1p-32);
-  coin = (real)o3 * s32;
-  return V3{(real)o0 * s32, (real)o1 * s32, (real)o2 * s32};
+  coin = (real)o2 * real(0x1p-32);
+  return ball_from_pair(o0, o1);
 }
-
+__device__ __forceinline__ void rng_scatter2(Rng &g, uint32_t k0, uint32_t k1, V3 &a, V3 &b) {
+  uint32_t o0, o1, o2, o3;
+  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
+  a = ball_from_pair(o0, o1);
+  b = ball_from_pair(o2, o3);
+}

@@ -65,9 +65,17 @@ def test_philox_requests():
     assert L.orc_philox_request(42, 1000, 7, 3, 0, 3) == w[3] / 2.0**32
     low = (w[0] & 0x7ff) | ((w[1] & 0x7ff) << 11) | ((w[2] & 0x3ff) << 22)
     assert L.orc_philox_request(42, 1000, 7, 3, 0, 4) == low / 2.0**32
-    # scatter candidate: 32 bits per coordinate, the coin in the spare word
-    for k in range(4):
-        assert L.orc_philox_request(42, 1000, 7, 3, 2, k) == w[k] / 2.0**32
+    # unit-ball candidates: 21 bits per coordinate, one candidate per pair of words; the first block
+    # of a bounce = one candidate (words 0, 1) + the coin (word 2); a later block = two candidates
+    def ball(lo, hi):
+        return [(lo >> 11) / 2.0**21, (hi >> 11) / 2.0**21, ((lo & 0x7ff) | ((hi & 0x3ff) << 11)) / 2.0**21]
+    first = ball(w[0], w[1])
+    for k in range(3):
+        assert L.orc_philox_request(42, 1000, 7, 3, 2, k) == first[k]
+    assert L.orc_philox_request(42, 1000, 7, 3, 2, 3) == w[2] / 2.0**32
+    later = ball(w[0], w[1]) + ball(w[2], w[3])
+    for k in range(6):
+        assert L.orc_philox_request(42, 1000, 7, 3, 3, k) == later[k]
     # reduced-round blocks differ from the 10-round ones (the KAT test pins the round function)
     out10 = (C.c_uint32 * 4)()
     L.orc_philox4x32((C.c_uint32 * 4)(3, 7, 1000, 0), (C.c_uint32 * 2)(42, 0), out10, 10)
