@@ -733,7 +733,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
 
   const size_t depth_slots = (size_t)(cfg->max_child_rays > 0 ? cfg->max_child_rays : 1);
   if ((rc = c->partials.ensure((size_t)n_items * 3 * sizeof(double))) ||
-      (rc = c->stack.ensure(depth_slots * (size_t)n_lanes * sizeof(uint32_t))) ||
+      (rc = c->stack.ensure(strict ? depth_slots * (size_t)n_lanes * sizeof(uint32_t) : 4)) ||  // strict build only
       (rc = c->counters.ensure(48 * sizeof(unsigned long long))))
     return rc;
 

@@ -27,10 +27,12 @@
 //         Leaves found during the walk are queued per lane and tested in a separate
 //         phase, so the box loop and the primitive loop are each SIMT-dense.
 //   * radiance.  The reference multiplies attenuations on the way back up the
-//     recursion, a1*(a2*(...*(an*sky))).  To reproduce that order bit for bit the
-//     lane records the material index of every bounce in a per-lane path stack in
-//     HBM ([bounce][lane], coalesced) and folds it from the end when the path
-//     escapes to the sky.  A path that ends black contributes an exact zero.
+//     recursion, a1*(a2*(...*(an*sky))).  The STRICT build reproduces that order bit for bit:
+//     the lane records the material index of every bounce in a per-lane path stack in HBM
+//     ([bounce][lane], coalesced) and folds it from the end when the path escapes to the sky.
+//     The FAST builds multiply forward — ((a1*a2)*...*an)*sky, a running product in registers,
+//     equal to a few ulps — and need neither the stack nor the unwind loop (+6.2 %).  A path
+//     that ends black contributes an exact zero.
 //   * RNG: Philox4x32-7 in REQUESTS, one block each, counter (request, sample, pixel,
 //     0), key = seed.  The first block of a sample carries the pixel jitter and the shutter
 //     time (21 bits each) AND the first lens-disk candidate (32 bits per coordinate); a
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   const DevScene &sc = P.sc;
   const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
   const unsigned lane = lane_id();
-  const uint32_t lane_g = blockIdx.x * blockDim.x + threadIdx.x;
+  [[maybe_unused]] const uint32_t lane_g = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t npix_local = (uint32_t)P.local_rows * (uint32_t)P.W;
 
   Image<LDS> im;
@@ -126,7 +128,13 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   V3 ro = {0, 0, 0}, rd = {0, 0, 1};
   real rtime = 0;
   int depth = 0;              // remaining child rays
-  int nb = 0;                 // bounces recorded on the path stack
+  [[maybe_unused]] int nb = 0;  // bounces recorded on the path stack
+#ifdef RTOW_FAST_MATH
+  // fast builds: the product of the attenuations so far, multiplied forward — ((a1*a2)*...)*sky
+  // instead of the reference's a1*(a2*(...*sky)), equal to a few ulps — so no path stack and no
+  // unwind loop.  The strict build keeps the stack: it reproduces the reference's order bit for bit.
+  V3 throughput = {1, 1, 1};
+#endif
   Rng g = {0, 0, 0};
   uint32_t nseg = 0, nnode = 0, nprim = 0;
   // end-of-launch sample donation (see "tail" below)
@@ -372,6 +380,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       rtime = jt * (ct1 - ct0) + ct0;
       depth = P.max_child_rays;
       nb = 0;
+#ifdef RTOW_FAST_MATH
+      throughput = {1, 1, 1};
+#endif
       need_sample = false;
     }
 
@@ -409,6 +420,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
           const int pid = best.prim;
           int mi, kind;
           real m_fuzz, m_ir;
+#ifdef RTOW_FAST_MATH
+          V3 m_att;
+#endif
           if constexpr (KERNEL >= 2) {
             const uint32_t o_sph = KERNEL == 3 ? sc.g_off_sph : sc.off_sph;
             const uint32_t o_mov = KERNEL == 3 ? sc.g_off_mov : sc.off_mov;
@@ -449,6 +463,10 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             mi = (int)im.u32(o_pmat + 4u * (uint32_t)pid);
             const uint32_t mr = o_mats + 48u * (uint32_t)mi;
             const double2 m1 = im.d2(mr + 16u), m2 = im.d2(mr + 32u);  // {att.z, fuzz}, {ir, kind|pad}
+#ifdef RTOW_FAST_MATH
+            const double2 m0 = im.d2(mr);  // {att.x, att.y}
+            m_att = V3{(real)m0.x, (real)m0.y, (real)m1.x};
+#endif
             m_fuzz = (real)m1.y;
             m_ir = (real)m2.x;
             kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
@@ -478,6 +496,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             }
             mi = sc.prim_mat[pid];
             const DevMaterial *m = sc.mats + mi;
+#ifdef RTOW_FAST_MATH
+            m_att = V3{(real)m->att[0], (real)m->att[1], (real)m->att[2]};
+#endif
             kind = m->kind;
             m_fuzz = (real)m->fuzz;
             m_ir = (real)m->ir;
@@ -525,7 +546,11 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
           if (absorbed) {
             need_sample = true;  // src/render.cpp:120: black
           } else {
+#ifdef RTOW_FAST_MATH
+            throughput = throughput * m_att;
+#else
             P.stack[(size_t)nb * P.n_lanes + lane_g] = (uint32_t)mi;
+#endif
             ++nb;
             --depth;
             ro = where;
@@ -537,6 +562,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         const V3 unit = normalize(rd);
         const real t = real(0.5) * (unit.y + real(+1.0));
         V3 c = (real(1.0) - t) * V3{1, 1, 1} + t * V3{real(0.5), real(0.7), real(1.0)};
+#ifdef RTOW_FAST_MATH
+        c = throughput * c;
+#else
         for (int q = nb - 1; q >= 0; --q) {
           const uint32_t smi = P.stack[(size_t)q * P.n_lanes + lane_g];
           if constexpr (KERNEL >= 2) {
@@ -548,7 +576,16 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             c = V3{(real)m->att[0], (real)m->att[1], (real)m->att[2]} * c;
           }
         }
-        acc = acc + to_f64(c);  // pixel_color += ray_color(...)
+#endif
+        {
+          // never fused with the multiply that produced `c`: a donated sample (end-of-launch tail)
+          // reaches its owner as a rounded colour, so a fused multiply-add here would make the
+          // pixel sum depend on which lane traced the sample (the empty asm hides `c` from the
+          // contraction pass)
+          V3d cd = to_f64(c);
+          asm volatile("" : "+v"(cd.x), "+v"(cd.y), "+v"(cd.z));
+          acc = acc + cd;  // pixel_color += ray_color(...)
+        }
         need_sample = true;
       }
       if (need_sample) {

@@ -492,3 +492,16 @@ def test_rtweekend_gpus_flag_partitions_like_one_device(ctx):
     # a device index that does not exist is an error, not a silent fallback
     bad = subprocess.run(base + ["--gpus", "64"], capture_output=True)
     assert bad.returncode != 0
+
+
+def test_fast_and_f32_builds_are_run_to_run_deterministic(ctx):
+    """The image must not depend on which lane traced which sample: work is handed out dynamically and
+    idle lanes take over samples at the end of a launch, so e.g. a multiply fused into the pixel
+    accumulate on one path only would show up here as last-bit differences between two runs."""
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    for prec in (rtow.F64_FAST, rtow.F32, rtow.F64_STRICT):
+        for kernel in (rtow.KERNEL_GRID, rtow.KERNEL_BVH):
+            cfg = rtow.make_config(480, 320, 6, 2, 50, seed=1, precision=prec, kernel=kernel)
+            a, _ = ctx.render(scene, cfg)
+            b, _ = ctx.render(scene, cfg)
+            assert np.array_equal(a, b), (prec, kernel, int((a != b).sum()))
