@@ -9,7 +9,7 @@ framebuffer strips are gathered to rank 0 with ONE torch.distributed gather
 Workload (BASELINE.json configs):
   N = 1 : configs[1]  cover scene (486 spheres), 1200x800, 100 spp, 50 bounces
   N > 1 : configs[2]  same scene, 500 spp, tile-split over N GPUs + RCCL gather
-Both use 4 samples per work item (nstreams = spp / 4), f64 arithmetic (the
+Both use 10 samples per work item (nstreams = spp / 10), f64 arithmetic (the
 reference is all-fp64), the fast (FMA-contracted) kernel build and seed 1.
 
 One JSON line on rank 0, with
@@ -44,10 +44,12 @@ import rtow  # noqa: E402
 import tiles  # noqa: E402
 
 W, ASPECT, DEPTH, SEED = 1200, 1.5, 50, 1
-# Samples per work item (= spp / nstreams).  Short items keep the end-of-launch tail short: a few
-# pixels whose paths keep bouncing to the 50-bounce cap make their items several times longer
-# than average, and the launch ends with them (measured: 4 -> 7.5, 10 -> 7.0, 100 -> 3.9 Gsamples/s).
-SAMPLES_PER_ITEM = int(os.environ.get("RTOW_BENCH_SPI", "4"))
+# Samples per work item (= spp / nstreams).  Short items shorten the end-of-launch tail, long items
+# save partial-sum traffic and item bookkeeping.  With the tail measures of the end of round 1
+# (queue ending on cheap rows, sample donation, no polling of the empty queue) the optimum moved
+# from 4 to 10: C2 (100 spp) 2 -> 8.44, 4 -> 9.38, 5 -> 9.46, 10 -> 9.54, 20 -> 8.96 Gsamples/s;
+# 500 spp on one GPU 4 -> 9.66, 10 -> 10.11, 20 -> 10.19 (scripts/spi_sweep_500.sh).
+SAMPLES_PER_ITEM = int(os.environ.get("RTOW_BENCH_SPI", "10"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_VALU_PEAK_TF = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 BYTES_PER_SPHERE = 32    # cx cy cz r^2 as f64 (16 B in f32, doubled for f64)
