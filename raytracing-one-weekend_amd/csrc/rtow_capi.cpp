@@ -776,6 +776,12 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.tile_w_log2 = tw;
   P.div_tpr_n = th ? (uint32_t)cfg->image_width >> tw : 1u;
   P.div_tpr = make_fastdiv(P.div_tpr_n);
+  P.n_tile_rows = th ? (uint32_t)rows >> th : 1u;
+  {
+    int eighths = 1;  // the top eighth of the image is traced last (RTOW_SKY_EIGHTHS: 0..8)
+    if (const char *e = std::getenv("RTOW_SKY_EIGHTHS")) eighths = std::min(std::max(std::atoi(e), 0), 8);
+    P.sky_rows = th ? P.n_tile_rows * (uint32_t)eighths / 8u : 0u;
+  }
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
   P.counters = (unsigned long long *)c->counters.p;

@@ -84,6 +84,7 @@ struct TraceParams {
   uint32_t tile_w_log2, tile_h_log2;
   FastDiv div_tpr;         // tiles per row = W >> tile_w_log2
   uint32_t div_tpr_n;      // the divisor itself
+  uint32_t n_tile_rows, sky_rows;  // tiled order: tile rows of this rank, and how many of the top ones come last
   double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests
