@@ -39,6 +39,7 @@ __device__ __forceinline__ float safe_inv(float d) {
 
 struct ImgOffsets {  // byte offsets of the id and record sections inside a scene image
   uint32_t ids, sph, mov, tri;
+  uint32_t fat;           // grid image: id + sphere record side by side per list entry (0 = none)
   uint32_t sph32, mov32;  // f32 build: binary32 copies of the sphere records (grid cells); `tri` then
                           // points at binary32 triangle records (48 B), the only triangle section
 };
@@ -79,6 +80,22 @@ template <bool LDS, bool SMALL>
 __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, ImgOffsets off,
                                           uint32_t first, uint32_t count, const RayForms &ray, Closest &best,
                                           uint32_t &nprim, int &last_id) {
+#ifndef RTOW_REAL_F32
+  if constexpr (SMALL) {
+    if (off.fat != 0u) {  // wave-uniform: one round of LDS reads per entry instead of id -> record
+      for (uint32_t k = 0; k < count; ++k) {
+        const uint32_t e = off.fat + 48u * (first + k);
+        const int id = (int)im.u32(e);
+        const double2 p0 = im.d2(e + 16u), p1 = im.d2(e + 32u);
+        if (id == last_id) continue;
+        last_id = id;
+        ++nprim;
+        sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+      }
+      return;
+    }
+  }
+#endif
   for (uint32_t k = 0; k < count; ++k) {
     const int id = (int)im.u32(off.ids + 4u * (first + k));
     // one-entry mailbox: a primitive spanning adjacent grid cells is listed in each of them
@@ -144,7 +161,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   const float slack = 1.00002f;   // relative slack on the far side of the interval
   float tmax32 = __builtin_huge_valf();
   const uint32_t END = (uint32_t)sc.n_nodes;  // skip links past the last node point here
-  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri, sc.off_sph32, sc.off_mov32};
+  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri, 0u, sc.off_sph32, sc.off_mov32};
   int last_id = -1;
   uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
   uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u;  // queued leaves (0 = empty), oldest first
