@@ -361,6 +361,9 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   if ((rc = upload(c->sph, sph)) || (rc = upload(c->sph_r, sph_r)) || (rc = upload(c->mov, mov)) ||
       (rc = upload(c->tri, tri)) || (rc = upload(c->prim_mat, pmat)) || (rc = upload(c->mats, mats)))
     return rc;
+  bool leaf_direct = false;
+  std::vector<double> tri_img;    // leaf-ordered copies (triangle meshes, host builder)
+  std::vector<int32_t> pmat_img;
   const double t_bvh0 = now_ms();
   if (c->builder == RTOW_BUILDER_DEVICE_LBVH) {
     // the tree is built in HBM from the record arrays just uploaded; the host only lays out
@@ -388,6 +391,22 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     double c_trav = 0.0;
     if (const char *e = std::getenv("RTOW_BVH_CT")) c_trav = std::atof(e);
     rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
+    if (ns == 0 && nm == 0 && !std::getenv("RTOW_NO_LEAF_ORDER")) {
+      // Triangle meshes: the image holds the triangle records and their material indices in LEAF order
+      // and the id list is the identity, so a leaf test reads its records directly instead of id ->
+      // record (one LDS / L2 round trip less per leaf, and leaf neighbours are memory neighbours:
+      // +10 % on the 96.8k-triangle mesh, whose image lives in global memory).  `best.prim` is then a
+      // leaf slot; shading reads the same permuted sections.  (Host builder only.)
+      tri_img.resize(tri.size());
+      pmat_img.resize(pmat.size());
+      for (size_t sl = 0; sl < bvh.prim.size(); ++sl) {
+        std::memcpy(&tri_img[sl * 12], &tri[(size_t)bvh.prim[sl] * 12], 96);
+        pmat_img[sl] = pmat[bvh.prim[sl]];
+      }
+      for (size_t sl = 0; sl < bvh.prim.size(); ++sl) bvh.prim[sl] = (int32_t)sl;
+      rtow::make_scene_image(bvh, sph, mov, tri_img, s->camera.origin, img, pmat_img, mats_bytes);
+      leaf_direct = true;
+    } else
     rtow::make_scene_image(bvh, sph, mov, tri, s->camera.origin, img, pmat, mats_bytes);
     if (!rtow::validate_scene_image(img, ns + nm + nt))
       return fail(RTOW_EINVAL, "internal error: scene image failed validation (BVH links)");
@@ -480,6 +499,7 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   ds.off_pmat = img.off_pmat;
   ds.off_mats = img.off_mats;
   ds.n_nodes = img.n_nodes;
+  ds.leaf_direct = leaf_direct ? 1 : 0;
   ds.gblob = (const unsigned char *)c->gblob.p;
   ds.gblob_bytes = c->gblob_bytes;
   ds.g_off_cells = gimg.off_cells;
@@ -512,7 +532,8 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   {
     Image32 b32;
     const bool device_tree = c->builder == RTOW_BUILDER_DEVICE_LBVH;
-    make_image32(device_tree ? nullptr : img.blob.data(), img.off_sph, sph, mov, tri, pmat, mats_bytes, b32);
+    make_image32(device_tree ? nullptr : img.blob.data(), img.off_sph, sph, mov, leaf_direct ? tri_img : tri,
+                 leaf_direct ? pmat_img : pmat, mats_bytes, b32);
     if ((rc = upload(c->blob32, b32.blob))) return rc;
     if (device_tree)  // nodes + ids exist only in HBM
       HIPCHK(hipMemcpy(c->blob32.p, c->blob.p, img.off_sph, hipMemcpyDeviceToDevice));

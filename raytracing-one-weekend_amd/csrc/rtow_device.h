@@ -51,6 +51,7 @@ struct DevScene {
   uint32_t off_sph32, off_mov32; // f32 build's image: binary32 sphere records (16 B / 32 B); its off_tri
                                  // points at binary32 triangle records (48 B)
   int32_t n_nodes;
+  int32_t leaf_direct;     // BVH image: records and material indices are in leaf order, ids = identity
   // scene image for the GRID kernel (rtow_grid.h): header, cells, ids, records
   const unsigned char *gblob;
   uint32_t gblob_bytes;

@@ -97,7 +97,7 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
   }
 #endif
   for (uint32_t k = 0; k < count; ++k) {
-    const int id = (int)im.u32(off.ids + 4u * (first + k));
+    const int id = (!SMALL && sc.leaf_direct) ? (int)(first + k) : (int)im.u32(off.ids + 4u * (first + k));
     // one-entry mailbox: a primitive spanning adjacent grid cells is listed in each of them
     if (id == last_id) continue;
     last_id = id;
