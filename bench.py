@@ -144,7 +144,10 @@ def main():
     H = rtow.image_height(W, ASPECT)
     spp = a.spp or (100 if world == 1 else 500)
     nstreams = max(1, spp // SAMPLES_PER_ITEM)
-    tile_rows = 4 if H % (4 * world) == 0 else 8
+    # strips of 8 rows (8x8-pixel tiles: +0.8 % over 16x4) when they deal out evenly, else 4
+    tile_rows = 8 if H % (8 * world) == 0 else (4 if H % (4 * world) == 0 else 8)
+    if os.environ.get("RTOW_BENCH_TILE_ROWS"):  # experiment knob: strip height (also the tile shape: 64 / rows wide)
+        tile_rows = int(os.environ["RTOW_BENCH_TILE_ROWS"])
     precision = {"fast": rtow.F64_FAST, "strict": rtow.F64_STRICT, "f32": rtow.F32}[a.precision]
     kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID}[a.kernel]
     split_samples = a.split == "samples" and world > 1
