@@ -169,13 +169,14 @@ inline void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   out[3] = c3;
 }
 
-// One request = one Philox block = four 32-bit words w0..w3:
-//   jitter+time : u = (w0,w1) and v = (w2,w3) mapped like the reference's doubles would
-//                 leave nothing for the shutter time, so this request takes 42 bits per
-//                 value instead: u, v, time = (w_k + 2^32 * bits(10k..10k+9 of w3)) * 2^-42
-//   disk        : y = (w0,w1), x = (w2,w3), each mapped like libstdc++ maps two mt19937 words
-//   scatter     : unit-ball candidate x,y,z = w0,w1,w2 * 2^-32; w3 * 2^-32 is the dielectric
-//                 coin, meaningful only in the FIRST candidate block of a bounce
+// One request = one Philox block = four 32-bit words w0..w3 (the layouts are restated at each
+// request_*() below and pinned word by word in tests/test_oracle_units.py):
+//   first block of a sample : u, v, time = top 21 bits of w0, w1, w2 (* 2^-21); first lens-disk
+//                             candidate = w3 and the 11+11+10 low bits of w0..w2 (* 2^-32 each)
+//   further lens-disk block : two candidates (w0, w1), (w2, w3), 32 bits per coordinate
+//   first block of a bounce : ONE unit-ball candidate from (w0, w1) — x, y = top 21 bits, z = the
+//                             11+10 low bits left over — and the dielectric coin w2 * 2^-32
+//   further scatter block   : two unit-ball candidates, (w0, w1) and (w2, w3)
 struct PhiloxDraw {
   uint64_t seed = 0;
   uint32_t pixel = 0, sample = 0, r = 0;

@@ -174,8 +174,44 @@ int grid_build_phase3(void *handle, const float gminf[3], const float cellf[3], 
 void grid_build_release(void *handle);
 }  // namespace rtow
 
+// Experiment knobs (RTOW_* environment variables), read ONCE at rtow_ctx_create: nothing on the
+// render path touches the environment.
+struct Knobs {
+  int bvh_leaf = 0;               // RTOW_BVH_LEAF: leaf size cap of the BVH builders (0 = default)
+  double bvh_ct = 0.0;            // RTOW_BVH_CT: SAH cost of descending one level
+  bool no_leaf_order = false;     // RTOW_NO_LEAF_ORDER
+  double grid_cpp = 1.5;          // RTOW_GRID_CPP: grid cells per primitive
+  double grid_large = 4.0;        // RTOW_GRID_LARGE: diagonal ratio that makes a primitive "large"
+  int grid_max_tris = 8192;       // RTOW_GRID_MAX_TRIS
+  unsigned long long partials_cap = 8ull << 30;  // RTOW_PARTIALS_MAX_MB
+  int bvh_block = 0;              // RTOW_BVH_BLOCK: 256 / 512 / 1024 (0 = automatic)
+  int blocks_per_cu = 0;          // RTOW_BLOCKS_PER_CU (0 = occupancy query)
+  bool no_tiles = false;          // RTOW_NO_TILES
+  int sky_eighths = 1;            // RTOW_SKY_EIGHTHS
+  bool stamps = false;            // RTOW_STAMPS: diagnostic region-stamp build
+  void read() {
+    auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
+    auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
+    bvh_leaf = geti("RTOW_BVH_LEAF", 0);
+    bvh_ct = getd("RTOW_BVH_CT", 0.0);
+    no_leaf_order = std::getenv("RTOW_NO_LEAF_ORDER") != nullptr;
+    grid_cpp = getd("RTOW_GRID_CPP", 1.5);
+    grid_large = getd("RTOW_GRID_LARGE", 4.0);
+    grid_max_tris = geti("RTOW_GRID_MAX_TRIS", 8192);
+    if (const char *e = std::getenv("RTOW_PARTIALS_MAX_MB")) partials_cap = (unsigned long long)std::atoll(e) << 20;
+    bvh_block = geti("RTOW_BVH_BLOCK", 0);
+    if (bvh_block != 256 && bvh_block != 512 && bvh_block != 1024) bvh_block = 0;
+    blocks_per_cu = geti("RTOW_BLOCKS_PER_CU", 0);
+    if (blocks_per_cu < 1 || blocks_per_cu > 16) blocks_per_cu = 0;
+    no_tiles = std::getenv("RTOW_NO_TILES") != nullptr;
+    sky_eighths = std::min(std::max(geti("RTOW_SKY_EIGHTHS", 1), 0), 8);
+    stamps = std::getenv("RTOW_STAMPS") != nullptr;
+  }
+};
+
 struct rtow_ctx {
   int device = 0;
+  Knobs knobs;
   int num_cus = 0;
   bool have_scene = false;
   rtow::DevScene ds{};
@@ -198,10 +234,9 @@ struct rtow_ctx {
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
   int occ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
-  hipEvent_t ev[kEventRing][2];
-  bool ev_ready = false;
+  hipEvent_t ev[kEventRing][2] = {};
   int ev_count = 0;
-  hipEvent_t call_ev[2];
+  hipEvent_t call_ev[2] = {};
   // pinned host mirror of the counters for stats
   unsigned long long *h_counters = nullptr;
 };
@@ -226,13 +261,20 @@ int rtow_ctx_create(int device_id, rtow_ctx **out) {
   rtow_ctx *c = new rtow_ctx();
   c->device = device_id;
   c->num_cus = prop.multiProcessorCount;
+  c->knobs.read();
   if (const char *e = std::getenv("RTOW_BUILDER"))
     c->builder = std::strcmp(e, "device") == 0 ? RTOW_BUILDER_DEVICE_LBVH : RTOW_BUILDER_HOST_SAH;
-  for (int i = 0; i < kEventRing; ++i)
-    for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreate(&c->ev[i][k]));
-  for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreate(&c->call_ev[k]));
-  c->ev_ready = true;
-  HIPCHK(hipHostMalloc((void **)&c->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  // every failure below releases what was created so far (rtow_ctx_destroy skips null handles)
+  hipError_t he = hipSuccess;
+  for (int i = 0; i < kEventRing && he == hipSuccess; ++i)
+    for (int k = 0; k < 2 && he == hipSuccess; ++k) he = hipEventCreate(&c->ev[i][k]);
+  for (int k = 0; k < 2 && he == hipSuccess; ++k) he = hipEventCreate(&c->call_ev[k]);
+  if (he == hipSuccess)
+    he = hipHostMalloc((void **)&c->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault);
+  if (he != hipSuccess) {
+    rtow_ctx_destroy(c);
+    return fail(RTOW_EHIP, "rtow_ctx_create: %s", hipGetErrorString(he));
+  }
   *out = c;
   return RTOW_OK;
 }
@@ -245,11 +287,11 @@ void rtow_ctx_destroy(rtow_ctx *c) {
                     &c->blob32, &c->gblob32, &c->cam32_dev,
                     &c->partials, &c->stack, &c->counters})
     b->release();
-  if (c->ev_ready) {
-    for (int i = 0; i < kEventRing; ++i)
-      for (int k = 0; k < 2; ++k) (void)hipEventDestroy(c->ev[i][k]);
-    for (int k = 0; k < 2; ++k) (void)hipEventDestroy(c->call_ev[k]);
-  }
+  for (int i = 0; i < kEventRing; ++i)
+    for (int k = 0; k < 2; ++k)
+      if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
+  for (int k = 0; k < 2; ++k)
+    if (c->call_ev[k]) (void)hipEventDestroy(c->call_ev[k]);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   rtow::lbvh_release(c->lbvh_scratch);
   rtow::grid_build_release(c->grid_scratch);
@@ -354,7 +396,7 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   // host SAH stops splitting by cost (mostly 1-2 primitives per leaf, cap 4); the radix tree has
   // no cost model, so its leaves are capped at 2 (measured: 1 and 2 equal, 4 is 8-17 % slower)
   int leaf_max = c->builder == RTOW_BUILDER_DEVICE_LBVH ? 2 : 4;
-  if (const char *e = std::getenv("RTOW_BVH_LEAF")) leaf_max = std::min(std::max(std::atoi(e), 1), 7);
+  if (c->knobs.bvh_leaf > 0) leaf_max = std::min(std::max(c->knobs.bvh_leaf, 1), 7);
   rtow::SceneImage img;
   std::vector<unsigned char> mats_bytes(mats.size() * sizeof(rtow::DevMaterial));
   std::memcpy(mats_bytes.data(), mats.data(), mats_bytes.size());
@@ -388,10 +430,9 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     if (brc) return fail(RTOW_EHIP, "device BVH emit failed (stage %d): %s", brc, hipGetErrorString(hipGetLastError()));
   } else {
     rtow::HostBvh bvh;
-    double c_trav = 0.0;
-    if (const char *e = std::getenv("RTOW_BVH_CT")) c_trav = std::atof(e);
+    const double c_trav = c->knobs.bvh_ct;
     rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
-    if (ns == 0 && nm == 0 && !std::getenv("RTOW_NO_LEAF_ORDER")) {
+    if (ns == 0 && nm == 0 && !c->knobs.no_leaf_order) {
       // Triangle meshes: the image holds the triangle records and their material indices in LEAF order
       // and the id list is the identity, so a leaf test reads its records directly instead of id ->
       // record (one LDS / L2 round trip less per leaf, and leaf neighbours are memory neighbours:
@@ -417,14 +458,11 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   c->bvh_nodes = img.n_nodes;
   // uniform grid over the small primitives (when the scene suits it)
   rtow::GridImage gimg;
-  double cpp = 1.5;
-  if (const char *e = std::getenv("RTOW_GRID_CPP")) cpp = std::atof(e);
-  double large_ratio = 4.0;
-  if (const char *e = std::getenv("RTOW_GRID_LARGE")) large_ratio = std::atof(e);
+  const double cpp = c->knobs.grid_cpp;
+  const double large_ratio = c->knobs.grid_large;
   // big meshes never take the grid (a triangle spans many cells: 0.4x the BVH):
   // skip the host build, a GRID request then falls back to the BVH
-  int grid_max_tris = 8192;
-  if (const char *e = std::getenv("RTOW_GRID_MAX_TRIS")) grid_max_tris = std::atoi(e);
+  const int grid_max_tris = c->knobs.grid_max_tris;
   bool grid_on_device = false;
   if (nt <= grid_max_tris && c->builder == RTOW_BUILDER_DEVICE_LBVH) {
     // the same grid, built in HBM (csrc/rtow_build_grid.hip); the host does the scalar steps between
@@ -663,8 +701,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   // tracing the streams in ranges that accumulate onto d_rgb_sums — bit-identical to one launch
   // (the reduce kernel adds stream sums in stream order either way).
   {
-    unsigned long long cap_bytes = 8ull << 30;
-    if (const char *e = std::getenv("RTOW_PARTIALS_MAX_MB")) cap_bytes = (unsigned long long)std::atoll(e) << 20;
+    const unsigned long long cap_bytes = c->knobs.partials_cap;
     const unsigned long long per_stream = npix * 24ull;
     unsigned long long max_streams = per_stream ? cap_bytes / per_stream : (unsigned long long)streams_now;
     if (per_stream && 0xfffffff0ULL / npix < max_streams) max_streams = 0xfffffff0ULL / npix;  // 32-bit item index
@@ -713,17 +750,13 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   const bool f32 = cfg->precision == RTOW_F32;
   const rtow::DevScene &scene = f32 ? c->ds32 : c->ds;
   int block = kernel >= RTOW_KERNEL_BVH ? kBvhBlock : kBlock;
-  if (kernel >= RTOW_KERNEL_BVH)
-    if (const char *e = std::getenv("RTOW_BVH_BLOCK")) {  // experiment knob
-      const int b = std::atoi(e);
-      if (b == 256 || b == 512 || b == 1024) block = b;
-    }
+  if (kernel >= RTOW_KERNEL_BVH && c->knobs.bvh_block) block = c->knobs.bvh_block;  // experiment knob
   // the scene image goes to LDS when one copy per workgroup fits (160 KiB per CU)
   const uint32_t image_bytes = kernel == RTOW_KERNEL_GRID ? scene.gblob_bytes : scene.blob_bytes;
   // an image too big for two workgroups per CU: ONE 1024-lane workgroup (16 waves, the same 4 per SIMD)
   // instead of one 512-lane workgroup (2 per SIMD)
   if (kernel >= RTOW_KERNEL_BVH && block == kBvhBlock && image_bytes <= kLdsLimit && 2u * image_bytes > kLdsLimit &&
-      !std::getenv("RTOW_BVH_BLOCK"))
+      !c->knobs.bvh_block)
     block = 1024;
   const unsigned lds_bytes = (kernel >= RTOW_KERNEL_BVH && image_bytes <= kLdsLimit) ? image_bytes : 0u;
 
@@ -748,10 +781,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
                  : rtow::trace_occupancy_fast(kernel, block, lds_bytes);
     if (occ <= 0) return fail(RTOW_EHIP, "occupancy query failed (kernel %d, %u B of LDS)", kernel, lds_bytes);
     if (occ > 8) occ = 8;
-    if (const char *e = std::getenv("RTOW_BLOCKS_PER_CU")) {  // experiment knob
-      const int b = std::atoi(e);
-      if (b >= 1 && b <= 16) occ = b;
-    }
+    if (c->knobs.blocks_per_cu) occ = c->knobs.blocks_per_cu;  // experiment knob
   }
   long long grid = (long long)c->num_cus * occ;
   const long long need_blocks = (long long)((n_items + block - 1) / block);
@@ -790,7 +820,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.div_ns = make_fastdiv((uint32_t)streams_now);
   // tile the pixel order when the geometry allows it (a tile never straddles two strips)
   uint32_t th = 0, tw = 0;
-  if (!std::getenv("RTOW_NO_TILES")) {
+  if (!c->knobs.no_tiles) {
     for (uint32_t h : {3u, 2u, 1u}) {
       const uint32_t hh = 1u << h, ww = 64u >> h;
       if (cfg->tile_rows % hh == 0 && rows % (int)hh == 0 && cfg->image_width % (int)ww == 0) {
@@ -806,8 +836,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.div_tpr = make_fastdiv(P.div_tpr_n);
   P.n_tile_rows = th ? (uint32_t)rows >> th : 1u;
   {
-    int eighths = 1;  // the top eighth of the image is traced last (RTOW_SKY_EIGHTHS: 0..8)
-    if (const char *e = std::getenv("RTOW_SKY_EIGHTHS")) eighths = std::min(std::max(std::atoi(e), 0), 8);
+    const int eighths = c->knobs.sky_eighths;  // the top eighth of the image is traced last (RTOW_SKY_EIGHTHS: 0..8)
     P.sky_rows = th ? P.n_tile_rows * (uint32_t)eighths / 8u : 0u;
   }
   P.partials = (double *)c->partials.p;
@@ -822,7 +851,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
   if (slot >= 0) HIPCHK(hipEventRecord(c->ev[slot][0], st));
   int launch_kernel = kernel;
-  if (kernel >= RTOW_KERNEL_BVH && lds_bytes > 0 && std::getenv("RTOW_STAMPS")) launch_kernel = kernel + 16;  // diagnostic
+  if (kernel >= RTOW_KERNEL_BVH && lds_bytes > 0 && c->knobs.stamps) launch_kernel = kernel + 16;  // diagnostic
   int lrc = strict ? rtow::launch_trace_strict(P, launch_kernel, (int)grid, block, lds_bytes, st)
             : f32  ? rtow::launch_trace_f32(P, launch_kernel, (int)grid, block, lds_bytes, st)
                    : rtow::launch_trace_fast(P, launch_kernel, (int)grid, block, lds_bytes, st);
@@ -977,6 +1006,7 @@ int rtow_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t
   if (rc) return rc;
   const int spp_eff = cfg->samples_per_pixel / cfg->nstreams * cfg->nstreams;  // src/render.cpp:185
   if (spp_eff <= 0) return fail(RTOW_EINVAL, "no effective samples (samples_per_pixel < nstreams)");
+  if (cfg->accumulate) return fail(RTOW_EINVAL, "rtow_render_rgb8 owns its sums: accumulate must be 0");
   if ((rc = rtow_scene_upload(c, scene))) return rc;
   const int rows = rtow_local_rows(cfg);
   const size_t n = (size_t)rows * cfg->image_width * 3;

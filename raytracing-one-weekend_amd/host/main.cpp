@@ -33,7 +33,7 @@ static void usage(const char *argv0) {
                "  --kernel auto|brute|bvh|grid  closest-hit strategy (default auto)\n"
                "  --builder host|device       BVH build: host SAH (default) or on the GPU (LBVH)\n"
                "  --p6                        binary P6 output, write_color on the device\n"
-               "  --general-obj               with -l: load every shape and fan-triangulate polygons\n"
+               "  --general-obj               with -l: load every shape, not only the first\n"
                "  --gpus INT                  tile-split over INT devices (--device is the first)\n";
 }
 

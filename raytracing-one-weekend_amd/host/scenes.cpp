@@ -139,8 +139,10 @@ Scene foo(const Config &cfg) {
     if (face.size() == 3) {
       world.primitives().add<rt::Triangle>(mesh.vertices[face[0]], mesh.vertices[face[1]],
                                            mesh.vertices[face[2]], boring_material);
-    } else if (general && face.size() > 3) {
-      // fan triangulation (v0, vi, vi+1), the order tinyobjloader's triangulate uses for convex faces
+    } else if (face.size() > 3) {
+      // The reference calls tinyobj 1.0.6's LoadObj with its default triangulate = true
+      // (src/main.cpp:109), so polygons reach its loop already cut into the fan (v0, vi, vi+1) and its
+      // "isn't a triangle" branch (:130) is only reachable for faces of fewer than three vertices.
       for (size_t i = 1; i + 1 < face.size(); ++i)
         world.primitives().add<rt::Triangle>(mesh.vertices[face[0]], mesh.vertices[face[i]],
                                              mesh.vertices[face[i + 1]], boring_material);

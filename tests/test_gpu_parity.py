@@ -465,7 +465,9 @@ def test_stream_ranges_are_chunked_automatically_and_bit_identical(ctx, monkeypa
     cfg = rtow.make_config(120, 80, 24, 12, 50, seed=2, precision=rtow.F64_STRICT)
     whole, sw = ctx.render(scene, cfg)
     monkeypatch.setenv("RTOW_PARTIALS_MAX_MB", "1")  # 120*80*24 B = 230 kB per stream -> 4 streams per launch
-    parts, sp = ctx.render(scene, cfg)
+    small = rtow.Context(0)  # the knobs are read once, when a context is created
+    parts, sp = small.render(scene, cfg)
+    small.close()
     assert np.array_equal(whole, parts)
     assert sp.samples == sw.samples and sp.segments == sw.segments
     ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)

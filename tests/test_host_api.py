@@ -46,8 +46,8 @@ def test_obj_scene_flattens_like_the_oracle():
 
 
 def test_obj_errors(tmp_path):
-    quad = tmp_path / "quad.obj"
-    quad.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    quad = tmp_path / "line.obj"  # (a quad is not an error: tinyobj triangulates it, src/main.cpp:109)
+    quad.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2\n")
     out = C.POINTER(rtow.Scene)()
     hc = rtow.HostConfig(0, 1.5, 0)
     L = rtow.lib()
@@ -120,14 +120,22 @@ def test_committed_bench_line_follows_the_contract():
 
 
 def test_general_obj_loads_all_shapes_and_triangulates(tmp_path, monkeypatch):
-    """Beyond the reference (which reads shapes[0] only and throws on a quad, src/main.cpp:115-133):
-    RTOW_GENERAL_OBJ=1 / --general-obj loads every shape and fan-triangulates polygons; relative
-    (negative) indices resolve against the vertices read so far."""
+    """The reference reads shapes[0] only (src/main.cpp:115) and gets polygons fan-triangulated by
+    tinyobj 1.0.6's default triangulate = true (src/main.cpp:109), which the default path restates.
+    Beyond the reference: RTOW_GENERAL_OBJ=1 / --general-obj loads every shape; relative (negative)
+    indices resolve against the vertices read so far.  A face of two vertices is the reference's
+    "isn't a triangle" error (:130)."""
     obj = tmp_path / "two_shapes.obj"
     obj.write_text("o first\nv -1 -1 0\nv 1 -1 0\nv 1 1 0\nv -1 1 0\nf 1 2 3 4\n"
                    "o second\nv -1 -1 -1\nv 1 -1 -1\nv 0 1 -1\nf -3 -2 -1\n")
+    first = rtow.HostScene.obj(obj)  # reference behaviour: first shape only, the quad as a fan
+    assert first.c.n_triangles == 2
+    t2 = np.ctypeslib.as_array(first.c.triangle_geom, shape=(2, 9))
+    assert np.array_equal(t2[0], [-1, -1, 0, 1, -1, 0, 1, 1, 0]) and np.array_equal(t2[1], [-1, -1, 0, 1, 1, 0, -1, 1, 0])
+    bad = tmp_path / "line.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nf 1 2\n")
     with pytest.raises(Exception):
-        rtow.HostScene.obj(obj)  # reference behaviour: a quad is an error
+        rtow.HostScene.obj(bad)
     monkeypatch.setenv("RTOW_GENERAL_OBJ", "1")
     sc = rtow.HostScene.obj(obj)
     assert sc.c.n_triangles == 3
