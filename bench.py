@@ -11,18 +11,35 @@ Workload (BASELINE.json configs):
   N > 1 : configs[2]  same scene, 500 spp, tile-split over N GPUs + RCCL gather
 Both use 10 samples per work item (nstreams = spp / 10), f64 arithmetic (the
 reference is all-fp64), the fast (FMA-contracted) kernel build and seed 1.
+`--workload moving|suzanne|mesh100k` times another BASELINE config with the same code
+(configs[3] = suzanne 1920x1080x256 spp, configs[4] = 96,800-triangle mesh 1920x1080x1024 spp);
+the default N = 1 run also appends them, shortened to a few steps, as `other_configs`.
+
+Launch: `python bench.py --gpus N` starts N ranks itself when it was not started by
+torchrun (WORLD_SIZE unset): the parent spawns N fresh worker processes BEFORE anything
+touches the GPU, relays rank 0's JSON line and exits non-zero if fewer than N devices are
+visible.  Under `python -m torch.distributed.run … bench.py --gpus N` the ranks are taken
+from the environment.  `--backend gloo` rehearses the N > 1 path on a one-GPU box (every
+rank on cuda:0, collectives through host memory; at most 6 ranks).
 
 One JSON line on rank 0, with
-  roofline     — SURVEY.md §8d's streaming model: algorithmic bytes per launch =
-                 ceil(segments/64) * N_prim * 32 B + W*H*24 B, divided by the trace
-                 kernel's mean duration measured with HIP events on the launch
-                 stream inside the timed region; peak = 8 TB/s HBM; `traffic` = HBM
-                 bytes per launch from the committed PMC passes (profiles/).  The
-                 scene is LDS resident, so the kernel is VALU-bound, not HBM-bound:
-                 `walk` gives what the kernel really reads (LDS) and computes.
-  cpu_baseline — oracle/ (the CPU restatement of the reference's sample loop, same
-                 Philox stream) timed on this host's cores on a bounded sample of
-                 the same workload (same scene and resolution, fewer spp).
+  roofline      — bound "hbm" (the metric's definition).  `achieved` is SURVEY.md §8d's
+                  EQUIVALENT STREAMING bandwidth: the bytes a brute-force kernel would stream
+                  (ceil(segments/64) * N_prim * record bytes + framebuffer) divided by the
+                  trace kernel's mean duration, measured with HIP events on the launch stream
+                  inside the timed region.  It is not what the kernel reads: the scene lives
+                  in LDS (or L2 for the big mesh), so `traffic` (HBM bytes per launch from the
+                  committed PMC passes) and `measured_frac` are hundreds of times smaller, and
+                  a better acceleration structure pushes `frac` past 1.
+  roofline_valu — the bound that binds: VALU issue.  `achieved` = the f64/f32 flops of the
+                  walk's own counted node and primitive tests per second (live), against the
+                  78.6 TFLOP/s f64 vector peak; `issue_utilisation` and `lane_activity` come
+                  from the committed PMC file named in `pmc_file` (same kernel, same workload).
+  end_to_end    — SURVEY.md §8d's region for one call of the host-buffer entry point
+                  (rtow_render: scene upload incl. acceleration build, kernels, D2H of f64 sums).
+  cpu_baseline  — oracle/ (the CPU restatement of the reference's sample loop, same
+                  Philox stream) timed on this host's cores on a bounded sample of
+                  the same workload (same scene and resolution, fewer spp).
 """
 from __future__ import annotations
 
@@ -30,7 +47,10 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 
@@ -43,19 +63,30 @@ import torch.distributed as dist  # noqa: E402
 import rtow  # noqa: E402
 import tiles  # noqa: E402
 
-W, ASPECT, DEPTH, SEED = 1200, 1.5, 50, 1
+SEED = 1
 # Samples per work item (= spp / nstreams).  Short items shorten the end-of-launch tail, long items
 # save partial-sum traffic and item bookkeeping.  With the tail measures of the end of round 1
 # (queue ending on cheap rows, sample donation, no polling of the empty queue) the optimum moved
 # from 4 to 10: C2 (100 spp) 2 -> 8.44, 4 -> 9.38, 5 -> 9.46, 10 -> 9.54, 20 -> 8.96 Gsamples/s;
 # 500 spp on one GPU 4 -> 9.66, 10 -> 10.11, 20 -> 10.19 (scripts/spi_sweep_500.sh).
 SAMPLES_PER_ITEM = int(os.environ.get("RTOW_BENCH_SPI", "10"))
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+MESH_SAMPLES_PER_ITEM = int(os.environ.get("RTOW_BENCH_MESH_SPI", "8"))
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_VALU_PEAK_TF = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-BYTES_PER_SPHERE = 32    # cx cy cz r^2 as f64 (16 B in f32, doubled for f64)
-FLOPS_PER_SPHERE_TEST = 23  # to the discriminant reject (src/common-model.cpp:70-75)
-BYTES_PER_NODE = 32      # f32 box + skip link + leaf word
-FLOPS_PER_BOX_TEST = 17  # 6 fma-slabs + min/max network
+N_SIMD = 1024
+# SURVEY.md §8d record sizes (f32 figure doubled for the f64 records this path computes on)
+BYTES_PER_PRIM = {"sphere": 32, "moving": 56, "triangle": 72}
+FLOPS_SPHERE_TEST = 23   # to the discriminant reject (src/common-model.cpp:70-75)
+FLOPS_TRI_TEST = 59      # src/common-model.cpp:106-115
+MAX_REHEARSAL_RANKS = 6  # processes that may share one GPU on the pool's boxes
+
+WORKLOADS = {
+    # name: (scene, width, aspect, spp, bounces, samples per item, BASELINE config)
+    "cover": ("cover", 1200, 1.5, 100, 50, SAMPLES_PER_ITEM, "configs[1]"),
+    "moving": ("moving", 1200, 1.5, 100, 50, SAMPLES_PER_ITEM, "configs[1] with moving spheres (the reference's default)"),
+    "suzanne": ("suzanne", 1920, 16 / 9, 256, 20, MESH_SAMPLES_PER_ITEM, "configs[3]"),
+    "mesh100k": ("mesh100k", 1920, 16 / 9, 1024, 20, MESH_SAMPLES_PER_ITEM, "configs[4]"),
+}
 
 
 def parse():
@@ -64,12 +95,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="cover")
     ap.add_argument("--no-scaling-base", action="store_true",
                     help="N=1: skip the extra configs[2] (500 spp) measurement on this GPU")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N=1: skip the shortened runs of the other BASELINE configs")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--precision", choices=["fast", "strict", "f32"], default="fast",
                     help="fast/strict: binary64 (the metric's arithmetic); f32: the preview build, never the headline")
     ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid"], default="auto")
-    ap.add_argument("--moving", action="store_true", help="moving-sphere variant of the cover scene")
+    ap.add_argument("--moving", action="store_true", help="same as --workload moving")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", choices=["tiles", "samples"], default="tiles",
                     help="N>1 decomposition: strips of rows + one gather (default, bit-identical for any N) "
@@ -77,7 +112,43 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = rehearsal of the N>1 path with every rank on cuda:0 (1-GPU box)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dump-image", default="", help="rank 0: write the gathered f64 sums of the last step (.npy)")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------ launching N ranks ---
+def launch_ranks(a) -> int:
+    """Parent of an N-rank run that was not started by torchrun.  Nothing here initialises the
+    GPU (device_count() does not, on this image): the workers are fresh processes."""
+    rehearsal = a.backend == "gloo"
+    n_dev = torch.cuda.device_count()
+    need = 1 if rehearsal else a.gpus
+    if n_dev < need:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} needs {need} HIP device(s), {n_dev} visible "
+                         f"(no CPU fallback; `--backend gloo` rehearses N ranks on one GPU)\n")
+        return 2
+    if rehearsal and a.gpus > MAX_REHEARSAL_RANKS:
+        sys.stderr.write(f"bench.py: a gloo rehearsal puts every rank on cuda:0; at most {MAX_REHEARSAL_RANKS} ranks\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed: {bad}\n")
+        return 1
+    return 0
 
 
 def host_cores():
@@ -95,43 +166,201 @@ def host_cores():
     return n
 
 
-def cpu_baseline(scene, height, seconds):
+def cpu_baseline(scene, label, W, height, depth, seconds):
     """Time the oracle (kind 'port') on this host: same scene/resolution, reduced spp."""
     sys.path.insert(0, str(ROOT / "tests"))
     import orc
 
     cores = host_cores()
-    cal = rtow.make_config(W, height, 2, 1, DEPTH, seed=SEED)
-    orc.render(scene, rtow.make_config(64, 48, 1, 1, DEPTH, seed=SEED), orc.RNG_PHILOX, nthreads=cores)  # warm up
+    cal = rtow.make_config(W, height, 2, 1, depth, seed=SEED)
+    orc.render(scene, rtow.make_config(64, 48, 1, 1, depth, seed=SEED), orc.RNG_PHILOX, nthreads=cores)  # warm up
     t0 = time.perf_counter()
     _, cst = orc.render(scene, cal, orc.RNG_PHILOX, nthreads=cores)
     dt = max(time.perf_counter() - t0, 1e-3)
     rate = cst.samples / dt  # samples per second of the oracle on this host
     spp = int(max(1, min(256, seconds * rate / (W * height))))
-    cfg = rtow.make_config(W, height, spp, 1, DEPTH, seed=SEED)
+    cfg = rtow.make_config(W, height, spp, 1, depth, seed=SEED)
     t0 = time.perf_counter()
     _, st = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=cores)
     dt = time.perf_counter() - t0
     return {
         "value": round(st.samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores,
         "kind": "port",
-        "sample": f"cover scene {W}x{height}, {spp} spp of the workload's spp, 50 bounces, "
+        "sample": f"{label} {W}x{height}, {spp} spp of the workload's spp, {depth} bounces, "
                   f"oracle/ (Philox stream) on {cores} threads, {dt:.1f} s",
     }
 
 
+# ------------------------------------------------------------------------- workloads ---
+def make_scene(kind):
+    """(HostScene, label).  Mesh scenes come from the committed suzanne fixture; the 96,800-triangle
+    mesh is its 10x10 subdivision (scripts/make_mesh.py; the reference's dragon.obj is absent)."""
+    if kind in ("cover", "moving"):
+        s = rtow.HostScene.cover(11, 1.5, kind == "moving")  # default mt19937 seed: 486 / 485 prims
+        return s, f"RTOW cover scene ({s.c.n_prims} prims, {'moving' if kind == 'moving' else 'static'})"
+    if kind == "suzanne":
+        s = rtow.HostScene.obj(ROOT / "tests" / "golden" / "suzanne.obj", 16 / 9)
+        return s, f"suzanne.obj triangle mesh ({s.c.n_prims} triangles)"
+    tmp = Path(tempfile.gettempdir()) / f"rtow_mesh100k_{os.getpid()}.obj"
+    subprocess.run([sys.executable, str(ROOT / "scripts" / "make_mesh.py"), str(tmp), "10"], check=True,
+                   capture_output=True)
+    try:
+        s = rtow.HostScene.obj(tmp, 16 / 9)
+    finally:
+        tmp.unlink(missing_ok=True)
+    return s, f"synthetic mesh, suzanne subdivided 10x10 ({s.c.n_prims} triangles; stands in for the absent dragon.obj)"
+
+
+def prim_model(scene):
+    c = scene.c
+    n = {"sphere": c.n_spheres, "moving": c.n_moving, "triangle": c.n_triangles}
+    bytes_all = sum(n[k] * BYTES_PER_PRIM[k] for k in n)
+    flops_all = (n["sphere"] + n["moving"]) * FLOPS_SPHERE_TEST + n["triangle"] * FLOPS_TRI_TEST
+    return n, bytes_all, flops_all
+
+
+KERNEL_NAMES = {1: "stream (every lane tests every primitive, scalar-load broadcast)",
+                2: "bvh (per-lane walk of the scene image in LDS, or in L2 when it does not fit)",
+                3: "grid (per-lane 3D-DDA over the LDS scene image + large-primitive list)"}
+
+
+def load_pmc(workload, precision, kernel_used):
+    """Derived PMC numbers of the committed profile of this workload/kernel (profiles/r02_pmc_*.json,
+    written by scripts/pmc_summary.py from separate rocprofv3 --pmc passes), or None."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_*.json")):
+        try:
+            pj = json.loads(f.read_text())
+        except Exception:
+            continue
+        d = pj.get("derived")
+        if not d or pj.get("workload") != workload or pj.get("precision") != precision or \
+                pj.get("kernel_used") != kernel_used:
+            continue
+        best = dict(d, pmc_file=f"profiles/{f.name}")
+    return best
+
+
+def rooflines(scene, st, kernel_ms, rows, W, workload, precision):
+    """The two roofline objects of one launch (this rank's)."""
+    n, bytes_all, flops_all = prim_model(scene)
+    seg = float(st.segments)
+    fb_bytes = rows * W * 24
+    alg_bytes = math.ceil(seg / 64) * bytes_all + fb_bytes
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    pmc = load_pmc(workload, precision, st.kernel_used)
+    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    roof = {
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "kernel": "rtow_trace_" + precision, "kernel_ms": round(kernel_ms, 4),
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "model": "EQUIVALENT STREAMING bandwidth, SURVEY.md §8d: ceil(segments/64) * sum(N_class * record bytes) "
+                 "+ rows*W*24 B; f64 records: sphere 32 B, moving sphere 56 B, triangle 72 B.  Not the bytes the "
+                 "kernel moves: the scene image is read from LDS (L2 for the 96.8k mesh), see measured_*",
+        "measured_hbm_GBps": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 1e9, 2),
+        "measured_frac": None if traffic is None else round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+    }
+    # what the kernel computes, from its own counters
+    if st.kernel_used == rtow.KERNEL_BRUTE:
+        flops = seg * flops_all
+        fmodel = "segments * sum(N_class * flops per test): sphere 23 (to the discriminant reject), triangle 59"
+        walk = None
+    else:
+        grid = st.kernel_used == rtow.KERNEL_GRID
+        nb, nf = (4, 12) if grid else (32, 17)
+        tri = n["triangle"] > 0
+        pb, pf = (96 + 0, FLOPS_TRI_TEST) if tri else (32 + 4, FLOPS_SPHERE_TEST)
+        flops = int(st.node_tests) * nf + int(st.prim_tests) * pf
+        walk = {
+            "image_bytes_read_per_launch": int(st.node_tests) * nb + int(st.prim_tests) * pb,
+            "flops_per_launch": flops,
+            "model": f"node_tests*{nb} B + prim_tests*{pb} B read from the scene image; node_tests*{nf} flop (f32 "
+                     + ("DDA step" if grid else "slab test") + f") + prim_tests*{pf} flop (f64)",
+        }
+        walk["image_GBps"] = round(walk["image_bytes_read_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1)
+        fmodel = walk["model"]
+    tf = flops / (kernel_ms * 1e-3) / 1e12
+    valu = {
+        "bound": "valu_issue", "achieved": round(tf, 3), "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
+        "frac": round(tf / F64_VALU_PEAK_TF, 5),
+        "model": "useful hit-test flops per second (counted by the kernel) vs the f64 vector peak; " + fmodel,
+        "issue_utilisation": pmc.get("valu_issue_utilisation") if pmc else None,
+        "lane_activity": pmc.get("lane_activity") if pmc else None,
+        "pmc_file": pmc.get("pmc_file") if pmc else None,
+        "pmc_note": "issue_utilisation = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); lane_activity = "
+                    "SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU*64); from separate rocprofv3 --pmc passes of this "
+                    "workload (null: no committed profile matches this workload/kernel)",
+    }
+    return roof, valu, walk
+
+
+def timed_render_loop(ctx, cfg, d_ptr, stream, dev, steps, warmup):
+    """Single-rank helper for the extra measurements: (ms per step, kernel ms, Stats)."""
+    import ctypes as C
+
+    st0 = ctx.render_device(cfg, d_ptr, stream, True)
+    for _ in range(max(warmup - 1, 0)):
+        ctx.render_device(cfg, d_ptr, stream, False)
+    torch.cuda.synchronize(dev)
+    L = rtow.lib()
+    L.rtow_profile_collect(ctx._h, None, None)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.render_device(cfg, d_ptr, stream, False)
+    torch.cuda.synchronize(dev)
+    el = (time.perf_counter() - t0) / steps
+    kms, nl = C.c_double(), C.c_int32()
+    rtow.check(L.rtow_profile_collect(ctx._h, C.byref(kms), C.byref(nl)), "profile_collect")
+    return el * 1e3, kms.value / max(nl.value, 1), st0
+
+
+def other_config(name, a, dev, precision, steps):
+    """One shortened line for another BASELINE config on this GPU (own context and scene)."""
+    kind, W, aspect, spp, depth, spi, base = WORKLOADS[name]
+    scene, label = make_scene(kind)
+    H = rtow.image_height(W, aspect)
+    cfg = rtow.make_config(W, H, spp, max(1, spp // spi), depth, seed=SEED, precision=precision)
+    ctx = rtow.Context(dev.index)
+    ctx.upload(scene)
+    bi = ctx.build_info()
+    out = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+    ms, kms, st = timed_render_loop(ctx, cfg, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream, dev, steps, 1)
+    roof, valu, walk = rooflines(scene, st, kms, H, W, name, a.precision)
+    line = {
+        "workload": f"{label} {W}x{H}, {spp} spp, {depth} bounces", "baseline_config": base,
+        "value": round(st.samples / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 4),
+        "steps": steps, "kernel_ms": round(kms, 4), "kernel": KERNEL_NAMES[st.kernel_used],
+        "scene_image_bytes": bi.grid_image_bytes if st.kernel_used == rtow.KERNEL_GRID else bi.bvh_image_bytes,
+        "build_ms": round(bi.bvh_build_ms + bi.grid_build_ms, 3),
+        "segments_per_sample": round(st.segments / st.samples, 4),
+        "node_tests_per_segment": round(st.node_tests / max(st.segments, 1), 3),
+        "prim_tests_per_segment": round(st.prim_tests / max(st.segments, 1), 3),
+        "roofline": roof, "roofline_valu": valu, "walk": walk,
+    }
+    ctx.close()
+    del out
+    return line
+
+
 def main():
     a = parse()
+    if a.moving:
+        a.workload = "moving"
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))  # nothing above touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     rehearsal = a.backend == "gloo"
     if rehearsal:
         local_rank = 0  # all ranks share the one GPU; collectives go through host memory
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: device {local_rank} not visible ({torch.cuda.device_count()} devices)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -141,9 +370,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    H = rtow.image_height(W, ASPECT)
-    spp = a.spp or (100 if world == 1 else 500)
-    nstreams = max(1, spp // SAMPLES_PER_ITEM)
+    kind, W, aspect, spp0, DEPTH, spi, base_cfg = WORKLOADS[a.workload]
+    H = rtow.image_height(W, aspect)
+    spp = a.spp or (spp0 if (world == 1 or kind not in ("cover", "moving")) else 500)
+    nstreams = max(1, spp // spi)
     # strips of 8 rows (8x8-pixel tiles: +0.8 % over 16x4) when they deal out evenly, else 4
     tile_rows = 8 if H % (8 * world) == 0 else (4 if H % (4 * world) == 0 else 8)
     if os.environ.get("RTOW_BENCH_TILE_ROWS"):  # experiment knob: strip height (also the tile shape: 64 / rows wide)
@@ -159,8 +389,7 @@ def main():
         cfg = rtow.make_config(W, H, spp, nstreams, DEPTH, seed=SEED, precision=precision,
                                kernel=kernel, rank=rank, nranks=world, tile_rows=tile_rows)
 
-    scene = rtow.HostScene.cover(11, ASPECT, a.moving)  # default mt19937 seed: 486 / 485 prims
-    n_prims = scene.c.n_prims
+    scene, label = make_scene(kind)
     ctx = rtow.Context(local_rank)
     ctx.upload(scene)  # scene resident in HBM before the timed region
 
@@ -173,13 +402,14 @@ def main():
         assert sg.rows == rows
     local = torch.zeros_like(sg.local, device=dev) if rehearsal else sg.local
     stream = torch.cuda.current_stream(dev)
+    last = {}
 
     def step(want_stats=False):
         st = ctx.render_device(cfg, local.data_ptr(), stream.cuda_stream, want_stats)
         if world > 1:
             if rehearsal:
                 sg.local.copy_(local)  # gloo has no device gather: stage through the host
-            sg.gather()  # the one collective: framebuffer strips -> rank 0 (RCCL gather)
+            last["image"] = sg.gather()  # the one collective: framebuffer strips -> rank 0 (RCCL gather)
         return st
 
     def fence():
@@ -216,44 +446,19 @@ def main():
     samples, segments = float(work[0]), float(work[1])
 
     if rank == 0:
+        if a.dump_image:
+            import numpy as np
+
+            img = last["image"] if world > 1 else local[: len(rows)]
+            np.save(a.dump_image, img.cpu().numpy())
         spp_eff = rtow.spp_effective(cfg)
         assert samples == W * H * spp_eff, (samples, W * H * spp_eff)
         ms_per_step = elapsed / a.steps * 1e3
         value = samples / (elapsed / a.steps) / 1e6
         # dominant kernel on THIS rank (rank 0): algorithmic bytes of its launch / its duration
         seg0 = float(st0.segments)
-        fb_bytes = len(rows) * W * 24
-        # SURVEY.md §8d, the figure the metric is defined on: one unit = a wave of 64 segments
-        # streaming the primitive array once (f64 records: 32 B per sphere) + the framebuffer.
-        alg_bytes = math.ceil(seg0 / 64) * n_prims * BYTES_PER_SPHERE + fb_bytes
-        alg_flops = seg0 * n_prims * FLOPS_PER_SPHERE_TEST
-        model = "ceil(segments/64)*N_prim*32B + rows*W*24B (SURVEY.md §8d streaming model, f64 records)"
-        fmodel = "segments*N_prim*23 flop (sphere test to the discriminant reject, streaming model)"
-        walked = None
-        if st0.kernel_used in (rtow.KERNEL_BVH, rtow.KERNEL_GRID):
-            # what the walking kernels really read and compute per launch (their own counters),
-            # all from the LDS scene image: BVH = a 32 B node per box test, GRID = a 4 B cell word
-            # per DDA step; both a 32 B record + 4 B id per primitive test
-            grid = st0.kernel_used == rtow.KERNEL_GRID
-            nb, nf = (4, 12) if grid else (BYTES_PER_NODE, FLOPS_PER_BOX_TEST)
-            walked = {
-                "lds_bytes_per_launch": int(st0.node_tests) * nb + int(st0.prim_tests) * (BYTES_PER_SPHERE + 4),
-                "flops_per_launch": int(st0.node_tests) * nf + int(st0.prim_tests) * FLOPS_PER_SPHERE_TEST,
-                "model": (f"node_tests*{nb}B + prim_tests*36B ; node_tests*{nf} flop (f32 "
-                          + ("DDA step" if grid else "slab") + ") + prim_tests*23 flop (f64)"),
-            }
-            walked["lds_GBps"] = round(walked["lds_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1)
-            walked["TFLOPs"] = round(walked["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12, 3)
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        prof = ROOT / "profiles" / "r01_hbm_traffic.json"
-        if prof.exists():
-            try:
-                pj = json.loads(prof.read_text())
-                if pj.get("workload_spp") == spp and pj.get("n_gpus") == world:
-                    traffic = pj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        roof, valu, walk = rooflines(scene, st0, kernel_ms, len(rows), W, a.workload, a.precision)
+        roof["kernel_ms_max_over_ranks"] = round(kernel_ms_max, 4)
         out = {
             "metric": "Msamples/sec (W×H×spp) on cover scene; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps,
@@ -262,39 +467,44 @@ def main():
             "dtype": "f64" if a.precision != "f32" else "f32 (preview build: NOT the metric's binary64 arithmetic)",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "config": {
-                "workload": f"RTOW cover scene ({n_prims} prims, {'moving' if a.moving else 'static'}) "
-                            f"{W}x{H}, {spp} spp, {DEPTH} bounces"
+                "workload": f"{label} {W}x{H}, {spp} spp, {DEPTH} bounces"
                             + ("" if world == 1 else
                                (f", sample-split over {world} GPUs + gather of full frames" if split_samples else
                                 f", {tile_rows}-row strips over {world} GPUs + 1 RCCL gather")),
-                "baseline_config": "configs[1]" if (world == 1 and spp == 100) else
-                                   ("configs[2]" if spp == 500 else "custom"),
+                "baseline_config": base_cfg if (world == 1 and spp == spp0) else
+                                   ("configs[2]" if (spp == 500 and kind == "cover") else "custom"),
                 "spp_effective": spp_eff, "samples_per_item": spp // nstreams, "nstreams": nstreams,
                 "seed": SEED, "precision": a.precision,
-                "kernel": {1: "stream (every lane tests every primitive, scalar-load broadcast)",
-                           2: "bvh (per-lane threaded walk of the LDS scene image)",
-                           3: "grid (per-lane 3D-DDA over the LDS scene image + large-primitive list)"}[st0.kernel_used],
+                "kernel": KERNEL_NAMES[st0.kernel_used],
                 "segments_per_sample": round(segments / samples, 4),
                 "node_tests_per_segment": round(st0.node_tests / max(seg0, 1), 3),
                 "prim_tests_per_segment": round(st0.prim_tests / max(seg0, 1), 3),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "rtow_trace_" + a.precision, "kernel_ms": round(kernel_ms, 4),
-                "kernel_ms_max_over_ranks": round(kernel_ms_max, 4),
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "model": model,
-            },
-            "walk": walked,
-            "roofline_valu": None if walked else {
-                "bound": "valu_f64", "achieved": round(alg_flops / (kernel_ms * 1e-3) / 1e12, 3),
-                "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(alg_flops / (kernel_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TF, 5),
-                "model": fmodel,
-            },
+            "roofline": roof,
+            "walk": walk,
+            "roofline_valu": valu,
         }
-        if world == 1 and spp == 100 and not a.no_scaling_base:
+        if world == 1 and not a.no_end_to_end:
+            # SURVEY.md §8d's region through the host-buffer entry point: scene upload (incl. the host
+            # build of the acceleration structure), kernels, D2H of the f64 sums into caller memory
+            import numpy as np
+
+            host = np.zeros((H, W, 3), dtype=np.float64)
+            ctx.render(scene, cfg, into=None)
+            t1 = time.perf_counter()
+            n_e2e = 3
+            for _ in range(n_e2e):
+                host, est = ctx.render(scene, cfg)
+            e1 = (time.perf_counter() - t1) / n_e2e
+            bi = ctx.build_info()
+            out["end_to_end"] = {
+                "value": round(W * H * spp_eff / e1 / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(e1 * 1e3, 4),
+                "calls": n_e2e, "upload_ms": round(bi.upload_ms, 3),
+                "build_ms": round(bi.bvh_build_ms + bi.grid_build_ms, 3),
+                "region": "rtow_render(): scene upload + acceleration build + trace + reduce + D2H of W*H*3 f64 sums "
+                          "into caller memory (SURVEY.md §8d; `value` above excludes upload and D2H)",
+            }
+        if world == 1 and a.workload == "cover" and spp == 100 and not a.no_scaling_base:
             # like-for-like base of the N>1 lines (configs[2], 500 spp): the same frame on this one
             # GPU, measured after the timed region (a longer launch amortises the end-of-launch tail)
             cfg5 = rtow.make_config(W, H, 500, 500 // SAMPLES_PER_ITEM, DEPTH, seed=SEED, precision=precision, kernel=kernel)
@@ -310,8 +520,11 @@ def main():
                 "value": round(W * H * 500 / e5 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(e5 * 1e3, 4),
                 "steps": 3,
             }
+        if world == 1 and a.workload == "cover" and not a.spp and not a.no_other_configs:
+            out["other_configs"] = [other_config(n, a, dev, precision, s)
+                                    for n, s in (("moving", 4), ("suzanne", 3), ("mesh100k", 2))]
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, H, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(scene, label, W, H, DEPTH, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -49,6 +49,14 @@ void orc_scene_free(rtow_scene_t *s);
 int orc_render(const rtow_scene_t *scene, const rtow_config_t *cfg, int rng_mode, int nthreads,
                double *rgb_sums, orc_stats_t *stats);
 
+/* The same render with the closest hit found through a tree of the checker's own when accel != 0
+ * (SAH build over exact f64 bounds, near-first descent) instead of the reference's median-split
+ * tree: same primitive tests, same image (tests/test_oracle_units.py compares the two bit for bit),
+ * ~100x faster on the 96,800-triangle mesh.  stats->node_tests / prim_tests then count the
+ * checker's tree, not the reference's. */
+int orc_render_ex(const rtow_scene_t *scene, const rtow_config_t *cfg, int rng_mode, int nthreads, int accel,
+                  double *rgb_sums, orc_stats_t *stats);
+
 /* write_color + P3 PPM text (src/render.cpp:11-20,182-186); free with orc_free. */
 int orc_ppm(const double *rgb_sums, int width, int height, int spp_effective, char **out_text,
             uint64_t *out_len);

@@ -52,6 +52,8 @@ def lib():
     L.orc_scene_free.restype = None
     L.orc_render.argtypes = [C.POINTER(rtow.Scene), C.POINTER(rtow.Config), C.c_int, C.c_int, _pd,
                              C.POINTER(OrcStats)]
+    L.orc_render_ex.argtypes = [C.POINTER(rtow.Scene), C.POINTER(rtow.Config), C.c_int, C.c_int, C.c_int, _pd,
+                                C.POINTER(OrcStats)]
     L.orc_ppm.argtypes = [_pd, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
                           C.POINTER(C.c_uint64)]
     L.orc_free.argtypes = [C.c_void_p]
@@ -118,16 +120,18 @@ class OrcScene:
             pass
 
 
-def render(scene, cfg: rtow.Config, rng_mode=RNG_PHILOX, nthreads=1, into=None):
-    """Returns (sums [rows, W, 3] float64, OrcStats).  `into`: sums to accumulate onto."""
+def render(scene, cfg: rtow.Config, rng_mode=RNG_PHILOX, nthreads=1, into=None, accel=False):
+    """Returns (sums [rows, W, 3] float64, OrcStats).  `into`: sums to accumulate onto.
+    `accel`: closest hit through the checker's own tree instead of the reference's (same image,
+    see oracle/rtow_oracle.h orc_render_ex; for renders at BASELINE sizes)."""
     s = scene.c if hasattr(scene, "c") else scene
     tile = max(cfg.tile_rows, 1)
     nr = max(cfg.nranks, 1)
     rows = sum(1 for i in range(cfg.image_height) if (i // tile) % nr == cfg.rank)
     out = np.zeros((rows, cfg.image_width, 3), dtype=np.float64) if into is None else into
     st = OrcStats()
-    rc = lib().orc_render(C.byref(s), C.byref(cfg), rng_mode, nthreads, out.ctypes.data_as(_pd),
-                          C.byref(st))
+    rc = lib().orc_render_ex(C.byref(s), C.byref(cfg), rng_mode, nthreads, int(bool(accel)),
+                             out.ctypes.data_as(_pd), C.byref(st))
     if rc != 0:
         raise RuntimeError(f"orc_render failed: {rc}")
     return out, st

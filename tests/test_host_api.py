@@ -161,3 +161,8 @@ def test_product_path_fails_loudly_without_a_hip_device():
     # bench.py refuses too
     b = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True)
     assert b.returncode != 0 and b"no CPU fallback" in b.stderr + b.stdout
+    # ... and `--gpus N` without N devices exits non-zero before starting any rank (never a silent 1-GPU run)
+    for extra in (["--gpus", "8"], ["--gpus", "2", "--backend", "gloo"]):
+        b = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0"] + extra,
+                           capture_output=True)
+        assert b.returncode != 0 and b"HIP device" in b.stderr and b"n_gpus" not in b.stdout

@@ -3,6 +3,7 @@ hand-computable cases, and properties of the Philox render mode."""
 import ctypes as C
 
 import numpy as np
+import pytest
 
 import orc
 import rtow
@@ -175,29 +176,117 @@ def test_philox_and_mt_images_agree_statistically():
     assert np.all(np.abs(ma - mb) < 0.01), (ma, mb)
 
 
-def test_t3_philox_vs_mt19937_rmse_against_two_independent_mt_runs():
-    """the counter-based stream against the reference's stream — RMSE <= 1.5x
-    the RMSE between two INDEPENDENT mt19937 renders (the second one made independent by burning
-    draws before render), and channel means within Monte-Carlo noise.  The device path is
-    bit-identical to the Philox oracle (GPU tests), so this carries over to it."""
-    spp, W, H = 32, 72, 48
+def _scene(kind):
+    from conftest import GOLDEN
+
+    if kind == "suzanne":
+        return orc.OrcScene.obj(GOLDEN / "suzanne.obj", 1.5), 20
+    return orc.OrcScene.cover(11, 1.5, kind == "moving"), 50
+
+
+@pytest.mark.parametrize("kind", ["static", "moving", "suzanne"])
+def test_checker_tree_gives_the_reference_tree_image_bit_for_bit(kind):
+    """orc_render_ex(accel=1) finds the closest hit through the checker's own SAH tree instead of
+    the reference's median-split tree (oracle/rtow_oracle.cpp, FastTree): same primitive tests, so
+    the same image, segment count and RNG consumption, in both RNG modes.  The GPU parity tests at
+    BASELINE sizes rely on this (the reference tree needs ~15,000 tests per segment on the
+    96,800-triangle mesh).  The mesh itself is compared the same way in tests/test_gpu_baseline_sizes.py
+    and below at a small size."""
+    scene, depth = _scene(kind)
+    for mode, nthreads in ((orc.RNG_PHILOX, 4), (orc.RNG_MT19937, 1)):
+        cfg = rtow.make_config(120, 80, 6, 2 if mode == orc.RNG_PHILOX else 1, depth, seed=3)
+        scene2, _ = _scene(kind)  # mt19937 mode: same generator state for both renders
+        a, sa = orc.render(scene2, cfg, mode, nthreads=nthreads)
+        scene3, _ = _scene(kind)
+        b, sb = orc.render(scene3, cfg, mode, nthreads=nthreads, accel=True)
+        assert np.array_equal(a, b), (kind, mode, int((a != b).sum()))
+        assert sa.segments == sb.segments and sa.rng_doubles == sb.rng_doubles
+        assert sb.prim_tests < sa.prim_tests  # it is a better tree
+
+
+def test_checker_tree_on_the_subdivided_mesh(tmp_path):
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    obj = tmp_path / "mesh.obj"
+    subprocess.run([sys.executable, str(REPO / "scripts" / "make_mesh.py"), str(obj), "10"], check=True,
+                   capture_output=True)
+    scene = orc.OrcScene.obj(obj, 16 / 9)
+    assert scene.c.n_triangles == 96800
+    cfg = rtow.make_config(1920, 1080, 1, 1, 20, seed=2, rank=137, nranks=540, tile_rows=2)
+    a, sa = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+    b, sb = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8, accel=True)
+    assert np.array_equal(a, b) and sa.segments == sb.segments
+    assert sb.prim_tests * 100 < sa.prim_tests
+
+
+@pytest.mark.parametrize("kind", ["static", "moving", "suzanne"])
+def test_t3_philox_vs_mt19937_rmse_against_two_independent_mt_runs(kind):
+    """SURVEY.md §8c T3 at the survey's bar: the counter-based stream (Philox4x32-7, 21-bit
+    quantised jitter and unit-ball candidates) against the reference's mt19937 stream
+    (src/random-utils.cpp:6-41) on 300x200x64 spp renders — per-channel means of the displayed
+    8-bit image within 0.5/255, and RMSE <= 1.5x the RMSE between two INDEPENDENT mt19937 renders
+    (the second one made independent by burning draws before render).  The device path is
+    bit-identical to the Philox oracle (GPU tests), so this carries over to it.  (Closest hits go
+    through the checker's tree, which the test above shows changes nothing.)"""
+    spp, W, H = 64, 300, 200
 
     def to8(img):
         return 256 * np.clip(np.sqrt(img / spp), 0.0, 0.999)
 
-    cfg = rtow.make_config(W, H, spp, 1, 50, seed=31)
-    s0 = orc.OrcScene.cover(11, 1.5, False)
-    a, _ = orc.render(s0, cfg, orc.RNG_MT19937)
-    s1 = orc.OrcScene.cover(11, 1.5, False)        # same scene (generator reset) ...
+    cfg = rtow.make_config(W, H, spp, 1, 50 if kind != "suzanne" else 20, seed=31)
+    s0, _ = _scene(kind)
+    a, _ = orc.render(s0, cfg, orc.RNG_MT19937, accel=True)
+    s1, _ = _scene(kind)                            # same scene (generator reset) ...
     orc.lib().orc_mt_burn(12345)                   # ... different render stream
-    b, _ = orc.render(s1, cfg, orc.RNG_MT19937)
-    c, _ = orc.render(s0, cfg, orc.RNG_PHILOX, nthreads=4)
-    assert np.array_equal(orc.scene_arrays(s0.c)["sphere_geom"], orc.scene_arrays(s1.c)["sphere_geom"])
+    b, _ = orc.render(s1, cfg, orc.RNG_MT19937, accel=True)
+    c, _ = orc.render(s0, cfg, orc.RNG_PHILOX, nthreads=8, accel=True)
+    for key in ("sphere_geom", "moving_geom", "triangle_geom"):
+        assert np.array_equal(orc.scene_arrays(s0.c)[key], orc.scene_arrays(s1.c)[key])
     rmse_ref = np.sqrt(np.mean((to8(a) - to8(b)) ** 2))
     rmse_phi = np.sqrt(np.mean((to8(a) - to8(c)) ** 2))
     assert rmse_phi <= 1.5 * rmse_ref, (rmse_phi, rmse_ref)
-    # means: the Monte-Carlo noise of an image mean at this size is ~0.3/255; allow 1/255
-    assert np.all(np.abs(to8(a).mean(axis=(0, 1)) - to8(c).mean(axis=(0, 1))) < 1.0)
+    d_ref = np.abs(to8(a).mean(axis=(0, 1)) - to8(b).mean(axis=(0, 1)))
+    d_phi = np.abs(to8(a).mean(axis=(0, 1)) - to8(c).mean(axis=(0, 1)))
+    assert np.all(d_phi < 0.5), (d_phi, d_ref)
+
+
+def test_unit_ball_candidates_are_uniform_per_coordinate():
+    """The 21-bit unit-ball mapping (csrc/rtow_trace_rng.h ball_from_pair, oracle PhiloxDraw): x and
+    y are the top 21 bits of two Philox words, z is assembled from the 11 + 10 LOW bits left over.
+    Each coordinate must be uniform on [0, 1) at every bit, z's low-order assembly included, and the
+    three must be uncorrelated — checked on 200,000 candidates of the first scatter block (kind 2)
+    and of the later blocks (kind 3, two candidates per block)."""
+    L = orc.lib()
+    n = 50_000
+    cols = []
+    for kind, ks in ((2, (0, 1, 2)), (3, (0, 1, 2)), (3, (3, 4, 5))):
+        v = np.array([[L.orc_philox_request(7, p, p % 13, 1 + p % 3, kind, k) for k in ks] for p in range(n)])
+        cols.append(v)
+    v = np.concatenate(cols)  # 150,000 x 3
+    assert v.min() >= 0.0 and v.max() < 1.0
+    q = np.round(v * 2**21).astype(np.int64)
+    assert np.array_equal(q / 2**21, v)  # exactly 21 bits per coordinate
+    m = len(v)
+    for c in range(3):
+        # mean and variance of U[0,1): 1/2 +- 5 sigma, 1/12
+        assert abs(v[:, c].mean() - 0.5) < 5 * np.sqrt(1 / 12 / m), (c, v[:, c].mean())
+        assert abs(v[:, c].var() - 1 / 12) < 0.002
+        # every one of the 21 bits is a fair coin (5 sigma)
+        for bit in range(21):
+            ones = ((q[:, c] >> bit) & 1).mean()
+            assert abs(ones - 0.5) < 5 * 0.5 / np.sqrt(m), (c, bit, ones)
+        # 64-bin chi-square (63 dof: mean 63, sd 11.2)
+        hist = np.bincount((v[:, c] * 64).astype(int), minlength=64)
+        chi = ((hist - m / 64) ** 2 / (m / 64)).sum()
+        assert chi < 63 + 6 * 11.3, (c, chi)
+    cc = np.corrcoef(v.T)
+    assert np.abs(cc[np.triu_indices(3, 1)]).max() < 5 / np.sqrt(m)
+    # acceptance rate of the rejection loop: volume of the unit ball's positive octant, pi/6
+    acc = (np.sum(v * v, axis=1) < 1.0).mean()
+    assert abs(acc - np.pi / 6) < 5 * np.sqrt(0.25 / m)
 
 
 def test_stream_ranges_and_accumulation_are_bit_identical_to_one_call():
