@@ -103,7 +103,7 @@ def parse():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--precision", choices=["fast", "strict", "f32"], default="fast",
                     help="fast/strict: binary64 (the metric's arithmetic); f32: the preview build, never the headline")
-    ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid", "bvh4"], default="auto")
     ap.add_argument("--moving", action="store_true", help="same as --workload moving")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", choices=["tiles", "samples"], default="tiles",
@@ -221,7 +221,8 @@ def prim_model(scene):
 
 KERNEL_NAMES = {1: "stream (every lane tests every primitive, scalar-load broadcast)",
                 2: "bvh (per-lane walk of the scene image in LDS, or in L2 when it does not fit)",
-                3: "grid (per-lane 3D-DDA over the LDS scene image + large-primitive list)"}
+                3: "grid (per-lane 3D-DDA over the LDS scene image + large-primitive list)",
+                4: "bvh4 (per-lane ordered walk of a 4-wide BVH, stack in LDS; image or its top levels in LDS)"}
 
 
 def load_pmc(workload, precision, kernel_used):
@@ -268,7 +269,9 @@ def rooflines(scene, st, kernel_ms, rows, W, workload, precision):
         walk = None
     else:
         grid = st.kernel_used == rtow.KERNEL_GRID
-        nb, nf = (4, 12) if grid else (32, 17)
+        # per node test: grid = one 4-byte cell word and a DDA step; BVH = one 32-byte node and a slab test;
+        # BVH4 = one 128-byte node (112 read) and four slab tests
+        nb, nf = (4, 12) if grid else ((112, 68) if st.kernel_used == rtow.KERNEL_BVH4 else (32, 17))
         tri = n["triangle"] > 0
         pb, pf = (96 + 0, FLOPS_TRI_TEST) if tri else (32 + 4, FLOPS_SPHERE_TEST)
         flops = int(st.node_tests) * nf + int(st.prim_tests) * pf
@@ -276,7 +279,8 @@ def rooflines(scene, st, kernel_ms, rows, W, workload, precision):
             "image_bytes_read_per_launch": int(st.node_tests) * nb + int(st.prim_tests) * pb,
             "flops_per_launch": flops,
             "model": f"node_tests*{nb} B + prim_tests*{pb} B read from the scene image; node_tests*{nf} flop (f32 "
-                     + ("DDA step" if grid else "slab test") + f") + prim_tests*{pf} flop (f64)",
+                     + ("DDA step" if grid else ("4 slab tests" if st.kernel_used == rtow.KERNEL_BVH4 else "slab test"))
+                     + f") + prim_tests*{pf} flop (f64)",
         }
         walk["image_GBps"] = round(walk["image_bytes_read_per_launch"] / (kernel_ms * 1e-3) / 1e9, 1)
         fmodel = walk["model"]
@@ -331,7 +335,8 @@ def other_config(name, a, dev, precision, steps):
         "workload": f"{label} {W}x{H}, {spp} spp, {depth} bounces", "baseline_config": base,
         "value": round(st.samples / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 4),
         "steps": steps, "kernel_ms": round(kms, 4), "kernel": KERNEL_NAMES[st.kernel_used],
-        "scene_image_bytes": bi.grid_image_bytes if st.kernel_used == rtow.KERNEL_GRID else bi.bvh_image_bytes,
+        "scene_image_bytes": bi.grid_image_bytes if st.kernel_used == rtow.KERNEL_GRID else
+                             (bi.bvh4_image_bytes if st.kernel_used == rtow.KERNEL_BVH4 else bi.bvh_image_bytes),
         "build_ms": round(bi.bvh_build_ms + bi.grid_build_ms, 3),
         "segments_per_sample": round(st.segments / st.samples, 4),
         "node_tests_per_segment": round(st.node_tests / max(st.segments, 1), 3),
@@ -379,7 +384,8 @@ def main():
     if os.environ.get("RTOW_BENCH_TILE_ROWS"):  # experiment knob: strip height (also the tile shape: 64 / rows wide)
         tile_rows = int(os.environ["RTOW_BENCH_TILE_ROWS"])
     precision = {"fast": rtow.F64_FAST, "strict": rtow.F64_STRICT, "f32": rtow.F32}[a.precision]
-    kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID}[a.kernel]
+    kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID,
+              "bvh4": rtow.KERNEL_BVH4}[a.kernel]
     split_samples = a.split == "samples" and world > 1
     if split_samples:
         s_first, s_count = tiles.stream_range(nstreams, world, rank)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTOW_ABI_VERSION 3
+#define RTOW_ABI_VERSION 4
 
 /* error codes */
 #define RTOW_OK 0
@@ -65,6 +65,10 @@ extern "C" {
 #define RTOW_KERNEL_BVH 2   /* every lane walks a threaded (stackless) BVH in LDS       */
 #define RTOW_KERNEL_GRID 3  /* every lane walks a uniform grid (3D-DDA) in LDS; falls back
                                to BVH when the scene does not suit a grid              */
+#define RTOW_KERNEL_BVH4 4  /* triangle meshes: every lane walks a 4-wide BVH, nearest child
+                               first, with a per-lane stack in LDS; the image (or the top of
+                               its tree) is staged in LDS.  Falls back to BVH for scenes with
+                               spheres, for the f32 preview build and for the device builder */
 
 /* Camera state: exactly the private members of the reference Camera after its
  * constructor ran (src/common-model.h:104-112, src/common-model.cpp:136-154). */
@@ -199,6 +203,8 @@ typedef struct rtow_build_info_t {
                                including its two small read-backs */
   double grid_build_ms;     /* host wall time */
   double upload_ms;         /* whole rtow_scene_upload call */
+  int32_t bvh4_nodes;       /* 4-wide BVH image (triangle meshes, host builder): nodes, 0 = none */
+  int32_t bvh4_image_bytes;
 } rtow_build_info_t;
 /* Facts about the last rtow_scene_upload of this context. */
 int rtow_build_info(rtow_ctx *ctx, rtow_build_info_t *out);

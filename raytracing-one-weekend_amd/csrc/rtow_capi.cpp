@@ -20,6 +20,7 @@
 
 #include "../../include/rtow.h"
 #include "rtow_bvh.h"
+#include "rtow_bvh4.h"
 #include "rtow_device.h"
 #include "rtow_grid.h"
 
@@ -189,6 +190,8 @@ struct Knobs {
   bool no_tiles = false;          // RTOW_NO_TILES
   int sky_eighths = 1;            // RTOW_SKY_EIGHTHS
   bool stamps = false;            // RTOW_STAMPS: diagnostic region-stamp build
+  bool no_bvh4 = false;           // RTOW_NO_BVH4: triangle meshes keep the binary threaded walk
+  int bvh4_stack_k = 0;           // RTOW_BVH4_STACK_K: LDS stack entries per lane (0 = as many as fit, <= 32)
   void read() {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
     auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
@@ -206,6 +209,8 @@ struct Knobs {
     no_tiles = std::getenv("RTOW_NO_TILES") != nullptr;
     sky_eighths = std::min(std::max(geti("RTOW_SKY_EIGHTHS", 1), 0), 8);
     stamps = std::getenv("RTOW_STAMPS") != nullptr;
+    no_bvh4 = std::getenv("RTOW_NO_BVH4") != nullptr;
+    bvh4_stack_k = std::min(std::max(geti("RTOW_BVH4_STACK_K", 0), 0), 64);
   }
 };
 
@@ -219,6 +224,9 @@ struct rtow_ctx {
   int n_prims = 0;
   // scene buffers
   DevBuf sph, sph_r, mov, tri, prim_mat, mats, blob, cam_dev, gblob;
+  DevBuf blob4;                        // 4-wide BVH image (triangle meshes)
+  bool have_bvh4 = false;
+  int bvh4_depth = 0;
   DevBuf blob32, gblob32, cam32_dev;  // the f32 build's scene images and camera
   rtow::DevScene ds32{};               // ds with the f32 images' pointers and offsets
   uint32_t gblob_bytes = 0;
@@ -230,9 +238,9 @@ struct rtow_ctx {
   void *grid_scratch = nullptr;
   rtow_build_info_t build_info{};
   // workspace
-  DevBuf partials, stack, counters;
+  DevBuf partials, stack, counters, spill;
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
-  int occ[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  int occ[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
   hipEvent_t ev[kEventRing][2] = {};
   int ev_count = 0;
@@ -284,8 +292,8 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
-                    &c->blob32, &c->gblob32, &c->cam32_dev,
-                    &c->partials, &c->stack, &c->counters})
+                    &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
+                    &c->partials, &c->stack, &c->counters, &c->spill})
     b->release();
   for (int i = 0; i < kEventRing; ++i)
     for (int k = 0; k < 2; ++k)
@@ -407,6 +415,9 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   std::vector<double> tri_img;    // leaf-ordered copies (triangle meshes, host builder)
   std::vector<int32_t> pmat_img;
   const double t_bvh0 = now_ms();
+  c->have_bvh4 = false;
+  c->build_info.bvh4_nodes = 0;
+  c->build_info.bvh4_image_bytes = 0;
   if (c->builder == RTOW_BUILDER_DEVICE_LBVH) {
     // the tree is built in HBM from the record arrays just uploaded; the host only lays out
     // the image sections around it
@@ -452,6 +463,28 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     if (!rtow::validate_scene_image(img, ns + nm + nt))
       return fail(RTOW_EINVAL, "internal error: scene image failed validation (BVH links)");
     if ((rc = upload(c->blob, img.blob))) return rc;
+    // triangle meshes: the 4-wide tree collapsed from the same SAH tree (rtow_bvh4.h)
+    c->have_bvh4 = false;
+    if (ns == 0 && nm == 0 && !c->knobs.no_bvh4) {
+      rtow::HostBvh bvh2;  // built again: the leaf-order pass above renumbered bvh.prim
+      rtow::build_bvh(sph, sph_r, mov, tri, bvh2, std::min(leaf_max, 4), c_trav, s->camera.t0, s->camera.t1);
+      rtow::Bvh4Image img4;
+      rtow::make_bvh4_image(bvh2, tri, pmat, mats_bytes, s->camera.origin, img4);
+      if (img4.ok) {
+        if (!rtow::validate_bvh4_image(img4, (size_t)nt))
+          return fail(RTOW_EINVAL, "internal error: 4-wide scene image failed validation");
+        if ((rc = upload(c->blob4, img4.blob))) return rc;
+        c->have_bvh4 = true;
+        c->bvh4_depth = img4.depth;
+        c->ds.blob4 = (const unsigned char *)c->blob4.p;
+        c->ds.blob4_bytes = (uint32_t)img4.blob.size();
+        c->ds.b4_off_tri = img4.off_tri;
+        c->ds.b4_off_pmat = img4.off_pmat;
+        c->ds.b4_off_mats = img4.off_mats;
+        c->build_info.bvh4_nodes = img4.n_nodes;
+        c->build_info.bvh4_image_bytes = (int32_t)img4.blob.size();
+      }
+    }
   }
   const double t_bvh1 = now_ms();
   c->blob_bytes = (uint32_t)img.total_bytes;
@@ -515,7 +548,7 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     if (!grid_on_device && (rc = upload(c->gblob, gimg.blob))) return rc;
     c->gblob_bytes = (uint32_t)(grid_on_device ? gimg.total_bytes : gimg.blob.size());
   }
-  for (auto &o : c->occ) o[0] = o[1] = o[2] = 0;
+  for (auto &o : c->occ) o[0] = o[1] = o[2] = o[3] = 0;
 
   rtow::DevScene &ds = c->ds;
   ds.sph = (const double *)c->sph.p;
@@ -633,7 +666,7 @@ static int validate_cfg(const rtow_config_t *cfg) {
   if (cfg->tile_rows <= 0) return fail(RTOW_EINVAL, "tile_rows must be >= 1");
   if (cfg->precision != RTOW_F64_STRICT && cfg->precision != RTOW_F64_FAST && cfg->precision != RTOW_F32)
     return fail(RTOW_EINVAL, "unknown precision %d", cfg->precision);
-  if (cfg->kernel < RTOW_KERNEL_AUTO || cfg->kernel > RTOW_KERNEL_GRID)
+  if (cfg->kernel < RTOW_KERNEL_AUTO || cfg->kernel > RTOW_KERNEL_BVH4)
     return fail(RTOW_EINVAL, "unknown kernel %d", cfg->kernel);
   if ((long long)cfg->image_width * cfg->image_height > 0x7fffffffLL)
     return fail(RTOW_EINVAL, "image too large");
@@ -742,13 +775,16 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   // AUTO: a handful of primitives is cheaper to stream than to walk; sphere scenes walk the
   // grid (measured 1.3x the BVH on the cover scene); triangle meshes walk the BVH (a triangle
   // spans many cells and its test is 3.5x a sphere's, so duplicates are expensive: 0.4x)
-  if (kernel == RTOW_KERNEL_AUTO)
-    kernel = c->n_prims <= 16 ? RTOW_KERNEL_BRUTE
-             : (c->have_grid && c->ds.n_tri == 0) ? RTOW_KERNEL_GRID : RTOW_KERNEL_BVH;
-  if (kernel == RTOW_KERNEL_GRID && !c->have_grid) kernel = RTOW_KERNEL_BVH;  // scene not suited to a grid
   const bool strict = cfg->precision == RTOW_F64_STRICT;
   const bool f32 = cfg->precision == RTOW_F32;
-  const rtow::DevScene &scene = f32 ? c->ds32 : c->ds;
+  const bool bvh4_ok = c->have_bvh4 && !f32;  // triangle mesh, host builder, binary64 build
+  if (kernel == RTOW_KERNEL_AUTO)
+    kernel = c->n_prims <= 16 ? RTOW_KERNEL_BRUTE
+             : (c->have_grid && c->ds.n_tri == 0) ? RTOW_KERNEL_GRID
+             : bvh4_ok ? RTOW_KERNEL_BVH4 : RTOW_KERNEL_BVH;
+  if (kernel == RTOW_KERNEL_GRID && !c->have_grid) kernel = RTOW_KERNEL_BVH;  // scene not suited to a grid
+  if (kernel == RTOW_KERNEL_BVH4 && !bvh4_ok) kernel = RTOW_KERNEL_BVH;
+  rtow::DevScene scene = f32 ? c->ds32 : c->ds;
   int block = kernel >= RTOW_KERNEL_BVH ? kBvhBlock : kBlock;
   if (kernel >= RTOW_KERNEL_BVH && c->knobs.bvh_block) block = c->knobs.bvh_block;  // experiment knob
   // the scene image goes to LDS when one copy per workgroup fits (160 KiB per CU)
@@ -758,7 +794,33 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   if (kernel >= RTOW_KERNEL_BVH && block == kBvhBlock && image_bytes <= kLdsLimit && 2u * image_bytes > kLdsLimit &&
       !c->knobs.bvh_block)
     block = 1024;
-  const unsigned lds_bytes = (kernel >= RTOW_KERNEL_BVH && image_bytes <= kLdsLimit) ? image_bytes : 0u;
+  unsigned lds_bytes = (kernel >= RTOW_KERNEL_BVH && image_bytes <= kLdsLimit) ? image_bytes : 0u;
+  int stack_bound = 0;
+  if (kernel == RTOW_KERNEL_BVH4) {
+    // One 1024-lane workgroup per CU.  LDS = [image, or the top of its tree][stack: K entries x 4 B per lane].
+    // A small mesh is staged whole and the stack takes what is left (at least 8 entries per lane);
+    // a big one gets 24 stack entries per lane and as many breadth-first nodes as fit beside them.
+    block = 1024;
+    const uint32_t per_entry = 4u * (uint32_t)block;
+    stack_bound = 3 * c->bvh4_depth + 1;
+    uint32_t K, staged;
+    if (scene.blob4_bytes + 8u * per_entry <= kLdsLimit) {
+      staged = scene.blob4_bytes;
+      K = std::min<uint32_t>((kLdsLimit - staged) / per_entry, 32u);
+    } else {
+      K = 24u;
+      staged = std::min<uint32_t>((kLdsLimit - K * per_entry) / 128u * 128u, scene.b4_off_tri);
+    }
+    if (c->knobs.bvh4_stack_k > 0 && (uint32_t)c->knobs.bvh4_stack_k * per_entry + (staged == scene.blob4_bytes ? staged : 0u) <= kLdsLimit) {
+      K = (uint32_t)c->knobs.bvh4_stack_k;
+      if (staged != scene.blob4_bytes) staged = std::min<uint32_t>((kLdsLimit - K * per_entry) / 128u * 128u, scene.b4_off_tri);
+    }
+    K = std::min<uint32_t>(K, (uint32_t)stack_bound);
+    scene.b4_lds_limit = staged;
+    scene.b4_stack_base = (staged + 15u) / 16u * 16u;
+    scene.b4_stack_k = K;
+    lds_bytes = scene.b4_stack_base + K * per_entry;
+  }
 
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
@@ -775,6 +837,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
 
   // grid: as many 256-lane blocks as stay resident, but no more than there are items
   int &occ = c->occ[strict ? 0 : (f32 ? 2 : 1)][kernel - 1];
+  if (kernel == RTOW_KERNEL_BVH4) occ = 0;  // its LDS footprint depends on the scene: query every time (cheap)
   if (occ <= 0) {
     occ = strict ? rtow::trace_occupancy_strict(kernel, block, lds_bytes)
           : f32  ? rtow::trace_occupancy_f32(kernel, block, lds_bytes)
@@ -794,6 +857,10 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
       (rc = c->stack.ensure(strict ? depth_slots * (size_t)n_lanes * sizeof(uint32_t) : 4)) ||  // strict build only
       (rc = c->counters.ensure(48 * sizeof(unsigned long long))))
     return rc;
+  if (kernel == RTOW_KERNEL_BVH4) {
+    const int extra = std::max(stack_bound - (int)scene.b4_stack_k, 0);
+    if ((rc = c->spill.ensure(std::max<size_t>((size_t)extra * (size_t)n_lanes * sizeof(uint32_t), 16)))) return rc;
+  }
 
   rtow::TraceParams P;
   std::memset(&P, 0, sizeof P);
@@ -841,6 +908,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   }
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
+  P.spill = (uint32_t *)c->spill.p;
   P.counters = (unsigned long long *)c->counters.p;
   P.t_origin = P.counters + 16;
 

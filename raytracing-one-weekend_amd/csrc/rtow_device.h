@@ -57,6 +57,14 @@ struct DevScene {
   uint32_t gblob_bytes;
   uint32_t g_off_cells, g_off_ids, g_off_sph, g_off_mov, g_off_tri, g_off_pmat, g_off_mats;
   uint32_t g_off_sph32, g_off_mov32;
+  // scene image for the BVH4 kernel (rtow_bvh4.h; triangle meshes): 128-byte nodes in breadth-first
+  // order, then triangle records in leaf order, material index per record, materials
+  const unsigned char *blob4;
+  uint32_t blob4_bytes;
+  uint32_t b4_off_tri, b4_off_pmat, b4_off_mats;
+  uint32_t b4_lds_limit;   // bytes of the image staged in LDS: all of it, or a 128-byte-aligned prefix of the nodes
+  uint32_t b4_stack_base;  // LDS byte offset of the traversal stack ([entry][lane of the workgroup], 4 B each)
+  uint32_t b4_stack_k;     // entries per lane in LDS; deeper entries go to TraceParams::spill
 };
 
 struct FastDiv {  // unsigned division by a per-launch constant (see fastdiv() in the kernel)
@@ -88,6 +96,7 @@ struct TraceParams {
   uint32_t n_tile_rows, sky_rows;  // tiled order: tile rows of this rank, and how many of the top ones come last
   double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
+  uint32_t *spill;         // BVH4 kernel: traversal stack entries beyond the LDS part, [entry][n_lanes]
   unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests
   unsigned long long *t_origin; // diagnostic build: earliest wave start (100 MHz clock)
 };

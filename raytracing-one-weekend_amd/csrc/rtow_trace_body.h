@@ -68,6 +68,7 @@ namespace {
 #include "rtow_trace_stamps.h"
 #include "rtow_trace_bvh.h"
 #include "rtow_trace_grid.h"
+#include "rtow_trace_bvh4.h"
 
 // --------------------------------------------------------------- the kernel ---
 // n / d for a divisor fixed per launch: q = (((n - t) >> 1) + t) >> shift, t = mulhi(n, magic)
@@ -96,7 +97,8 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// KERNEL: 1 = STREAM, 2 = BVH;  LDS: scene image staged in LDS (BVH only)
+// KERNEL: 1 = STREAM, 2 = BVH, 3 = GRID, 4 = BVH4;  LDS: scene image staged in LDS (2 and 3; the
+// BVH4 kernel always uses LDS: the image or its top, and the traversal stack)
 template <int KERNEL, bool LDS, bool STAMPS = false>
 __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const TraceParams P) {
@@ -108,7 +110,16 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
 
   Image<LDS> im;
   im.g = KERNEL == 3 ? sc.gblob : sc.blob;
-  if constexpr (KERNEL >= 2 && LDS) {
+  [[maybe_unused]] Bvh4Reader<LDS> im4;  // LDS: the whole image is staged; otherwise the top of the tree
+  if constexpr (KERNEL == 4) {
+    im4.g = sc.blob4;
+    im4.lds_limit = sc.b4_lds_limit;
+    const uint4 *src = reinterpret_cast<const uint4 *>(sc.blob4);
+    uint4 *dst = reinterpret_cast<uint4 *>(rtow_lds);
+    const uint32_t n16 = sc.b4_lds_limit / 16u;
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  } else if constexpr (KERNEL >= 2 && LDS) {
     // stage the scene image: coalesced 16-byte loads, 16-byte LDS stores
     const uint4 *src = reinterpret_cast<const uint4 *>(im.g);
     uint4 *dst = reinterpret_cast<uint4 *>(rtow_lds);
@@ -399,7 +410,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     Closest best;
     best.t = 0;
     best.prim = -1;
-    if constexpr (KERNEL == 3) {
+    if constexpr (KERNEL == 4) {
+      best = closest_hit_bvh4<LDS, STAMPS>(im4, sc, P, ro, rd, rtime, live, lane_g, nnode, nprim, stamps);
+    } else if constexpr (KERNEL == 3) {
       best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
     } else if constexpr (KERNEL == 2) {
       // the walk uses wave votes, so every lane of the wave enters it
@@ -427,7 +440,22 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
 #ifdef RTOW_FAST_MATH
           V3 m_att;
 #endif
-          if constexpr (KERNEL >= 2) {
+          if constexpr (KERNEL == 4) {
+            // triangles only: the un-normalised normal e1 x e2 of the record (src/common-model.cpp:121)
+            const uint32_t r = sc.b4_off_tri + 96u * (uint32_t)pid;
+            const vd2 q4 = im4.d2(r + 64u), q5 = im4.d2(r + 80u);
+            normal = {(real)q4.y, (real)q5.x, (real)q5.y};
+            mi = (int)im4.u32(sc.b4_off_pmat + 4u * (uint32_t)pid);
+            const uint32_t mr = sc.b4_off_mats + 48u * (uint32_t)mi;
+            const vd2 m1 = im4.d2(mr + 16u), m2 = im4.d2(mr + 32u);  // {att.z, fuzz}, {ir, kind|pad}
+#ifdef RTOW_FAST_MATH
+            const vd2 m0 = im4.d2(mr);  // {att.x, att.y}
+            m_att = V3{(real)m0.x, (real)m0.y, (real)m1.x};
+#endif
+            m_fuzz = (real)m1.y;
+            m_ir = (real)m2.x;
+            kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
+          } else if constexpr (KERNEL >= 2) {
             const uint32_t o_sph = KERNEL == 3 ? sc.g_off_sph : sc.off_sph;
             const uint32_t o_mov = KERNEL == 3 ? sc.g_off_mov : sc.off_mov;
             const uint32_t o_tri = KERNEL == 3 ? sc.g_off_tri : sc.off_tri;
@@ -571,7 +599,11 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
 #else
         for (int q = nb - 1; q >= 0; --q) {
           const uint32_t smi = P.stack[(size_t)q * P.n_lanes + lane_g];
-          if constexpr (KERNEL >= 2) {
+          if constexpr (KERNEL == 4) {
+            const uint32_t mr = sc.b4_off_mats + 48u * smi;
+            const vd2 a0 = im4.d2(mr), a1 = im4.d2(mr + 16u);
+            c = V3{(real)a0.x, (real)a0.y, (real)a1.x} * c;
+          } else if constexpr (KERNEL >= 2) {
             const uint32_t mr = (KERNEL == 3 ? sc.g_off_mats : sc.off_mats) + 48u * smi;
             const double2 a0 = im.d2(mr), a1 = im.d2(mr + 16u);
             c = V3{(real)a0.x, (real)a0.y, (real)a1.x} * c;
@@ -672,6 +704,10 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
                        : launch_one<2, false, false>(p, grid, block, 0, st);
     case 3: return lds ? launch_one<3, true, false>(p, grid, block, lds_bytes, st)
                        : launch_one<3, false, false>(p, grid, block, 0, st);
+    case 4: return p.sc.b4_lds_limit == p.sc.blob4_bytes ? launch_one<4, true, false>(p, grid, block, lds_bytes, st)
+                                                         : launch_one<4, false, false>(p, grid, block, lds_bytes, st);
+    case 4 + 16: return p.sc.b4_lds_limit == p.sc.blob4_bytes ? launch_one<4, true, true>(p, grid, block, lds_bytes, st)
+                                                              : launch_one<4, false, true>(p, grid, block, lds_bytes, st);
     case 2 + 16: return launch_one<2, true, true>(p, grid, block, lds_bytes, st);
     case 3 + 16: return launch_one<3, true, true>(p, grid, block, lds_bytes, st);
     default: return (int)hipErrorInvalidValue;
@@ -686,7 +722,9 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
 int RTOW_CAT(trace_occupancy_, RTOW_SUFFIX)(int kernel, int block, unsigned lds_bytes) {
   const void *fn;
   const bool lds = lds_bytes > 0;
-  if (kernel == 3)
+  if (kernel == 4)  // (both variants have the same launch bounds; the full-LDS one stands for both)
+    fn = reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<4, true, false>);
+  else if (kernel == 3)
     fn = lds ? reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<3, true, false>)
              : reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<3, false, false>);
   else if (kernel == 2)

@@ -17,12 +17,12 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 LIB_PATH = Path(os.environ.get("RTOW_LIB", PKG_DIR / "librtow.so"))  # RTOW_LIB: A/B against another build
 
-RTOW_ABI_VERSION = 3
+RTOW_ABI_VERSION = 4
 RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY = 0, -1, -2, -3, -4, -5
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
 F64_STRICT, F64_FAST, F32 = 0, 1, 2
-KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH, KERNEL_GRID = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH, KERNEL_GRID, KERNEL_BVH4 = 0, 1, 2, 3, 4
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1
 
 d3 = C.c_double * 3
@@ -82,6 +82,7 @@ class BuildInfo(C.Structure):
         ("builder", C.c_int32), ("bvh_nodes", C.c_int32),
         ("bvh_image_bytes", C.c_int32), ("grid_image_bytes", C.c_int32),
         ("bvh_build_ms", C.c_double), ("grid_build_ms", C.c_double), ("upload_ms", C.c_double),
+        ("bvh4_nodes", C.c_int32), ("bvh4_image_bytes", C.c_int32),
     ]
 
 
@@ -115,6 +116,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # Load-order guard: torch bundles its own copy of the HIP runtime, librtow.so links /opt/rocm's.  Both
+    # live in one process whenever torch supplies device memory and streams (bench.py, some tests); that is
+    # reliable when torch's libraries are mapped FIRST (bench.py's order) and was not the other way round
+    # ("No HIP GPUs are available" / "no ROCm-capable device" from whichever runtime came second).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not LIB_PATH.exists():
         raise RtowError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
                         " (there is no CPU fallback)")

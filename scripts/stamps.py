@@ -9,10 +9,10 @@ import rtow
 which = sys.argv[1] if len(sys.argv) > 1 else "cover"
 if which == "suzanne":
     scene = rtow.HostScene.obj(ROOT / "tests/golden/suzanne.obj")
-    cfg = rtow.make_config(1920, 1080, 16, 2, 20, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
+    cfg = rtow.make_config(1920, 1080, 16, 2, 20, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3, 'bvh4': 4}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
 else:
     scene = rtow.HostScene.cover(11, 1.5, which == "moving")
-    cfg = rtow.make_config(1200, 800, 100, int(os.environ.get('RTOW_NSTREAMS', '10')), 50, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
+    cfg = rtow.make_config(1200, 800, 100, int(os.environ.get('RTOW_NSTREAMS', '10')), 50, seed=1, precision=rtow.F64_FAST, kernel={'auto': 0, 'bvh': 2, 'grid': 3, 'bvh4': 4}[os.environ.get('RTOW_STAMP_KERNEL', 'auto')])
 ctx = rtow.Context(0)
 img, st = ctx.render(scene, cfg)
 out = (C.c_ulonglong * 48)()

@@ -128,7 +128,7 @@ def test_c4_suzanne_strips_strict_bitwise_and_fast_within_tolerance(ctx):
     assert scene.c.n_triangles == 968
     recheck_checker_tree(scene, C4, 67)
     for r, img, st, fast, ref, ost in strips(ctx, scene, C4):
-        assert st.kernel_used == rtow.KERNEL_BVH
+        assert st.kernel_used == rtow.KERNEL_BVH4
         assert st.segments == ost.segments, r
         assert np.array_equal(img, ref), (r, int((img != ref).sum()))
         check_fast(fast, ref, 256, ("C4 fast", r))
@@ -141,7 +141,7 @@ def test_c5_mesh100k_strips_strict_bitwise_and_fast_within_tolerance(ctx, mesh_o
     assert scene.c.n_triangles == 96800
     recheck_checker_tree(scene, C5, 135)
     for r, img, st, fast, ref, ost in strips(ctx, scene, C5):
-        assert st.kernel_used == rtow.KERNEL_BVH
+        assert st.kernel_used == rtow.KERNEL_BVH4
         assert st.segments == ost.segments, r
         assert np.array_equal(img, ref), (r, int((img != ref).sum()))
         check_fast(fast, ref, 1024, ("C5 fast", r))

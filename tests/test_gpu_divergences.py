@@ -66,6 +66,7 @@ def scene_of(cam, spheres=(), triangles=(), materials=()):
 
 LAMB = lambda rgb: (rtow.MAT_LAMBERTIAN, rgb, 0.0, 0.0)
 KERNELS = (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_GRID)
+TRI_KERNELS = (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_GRID, rtow.KERNEL_BVH4)  # triangle-only scenes
 
 
 def device_images(ctx, sc, cfgargs, kernels=KERNELS):
@@ -91,14 +92,14 @@ def test_zero_thickness_leaf_box_the_reference_never_hits_a_flat_leaf(ctx):
     flat, k1 = scene_of(cam, triangles=[(-1, -1, 0, 1, -1, 0, 0, 1, 0, 0)], materials=[LAMB((0.8, 0.3, 0.3))])
     ref, ost = orc.render(flat, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
     assert ost.segments == ost.samples  # the reference: every ray misses, pure sky
-    img, st = device_images(ctx, flat, args)
+    img, st = device_images(ctx, flat, args, kernels=TRI_KERNELS)
     assert st.segments > st.samples and not np.array_equal(img, ref)  # the device: the triangle is there
     # the device image is what the reference's own hit test gives once its box has thickness:
     # the same triangle and camera translated by +0.25 in z (exactly representable)
     cam2 = camera((0.3, 0.2, 3.25), (0, 0, 0.25), (0, 1, 0), 40.0, 1.5)
     lifted, k2 = scene_of(cam2, triangles=[(-1, -1, 0.25, 1, -1, 0.25, 0, 1, 0.25, 0)], materials=[LAMB((0.8, 0.3, 0.3))])
     ref2, ost2 = orc.render(lifted, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
-    img2, st2 = device_images(ctx, lifted, args)
+    img2, st2 = device_images(ctx, lifted, args, kernels=TRI_KERNELS)
     assert np.array_equal(img2, ref2) and st2.segments == ost2.segments
     assert st2.segments > st2.samples
 
@@ -106,29 +107,40 @@ def test_zero_thickness_leaf_box_the_reference_never_hits_a_flat_leaf(ctx):
 def test_exact_ties_in_t_resolve_like_the_reference_leaf_scan(ctx):
     """Two coincident primitives with different materials: every hit is an exact tie in t.  The reference's
     leaf scan accepts `t <= tmax` (src/common-model.cpp:76,115 via the shrinking tmax of src/render.cpp:57-65),
-    so the LATER primitive of the leaf wins; with <= 6 primitives the whole scene is one leaf in insertion
-    order.  Device: the same rule in its own test order (ascending primitive id inside a leaf, a cell or the
-    stream) — equal to the reference here, for both orders of insertion.  (In larger scenes the reference's
-    winner depends on its std::sort; so it would on the device's builder.  Neither is specified.)"""
+    so the LATER primitive in ITS traversal order wins; with <= 6 primitives the whole scene is one leaf in
+    insertion order, in larger scenes the order is whatever its std::sort left.
+    Device: the same `<=` rule in each kernel's own test order.  STREAM (ascending primitive id) and GRID
+    (large list, then cells in ascending id) reproduce the reference's one-leaf order exactly.  The BVH kernel
+    tests leaves in its tree's fixed depth-first order, so ONE of the two coincident primitives wins for every
+    ray — the image is the reference image of one of the two insertion orders (checked: which one depends on
+    the builder, as it does on std::sort in the reference; neither is specified behaviour)."""
     cam = camera((0, 0.5, 4.0), (0, 0, 0), (0, 1, 0), 35.0, 1.5)
     args = (90, 60, 6, 2, 8, 11)
     red, blue = LAMB((0.9, 0.1, 0.1)), LAMB((0.1, 0.1, 0.9))
     tri = (-1.5, -1, 0.5, 1.5, -1, 0.5, 0, 1.2, 0.5)
-    images = []
-    for order in ((0, 1), (1, 0)):
-        sc, keep = scene_of(cam, triangles=[tri + (order[0],), tri + (order[1],)], materials=[red, blue])
-        ref, ost = orc.render(sc, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
-        img, st = device_images(ctx, sc, args, kernels=(rtow.KERNEL_BRUTE, rtow.KERNEL_BVH))
-        assert np.array_equal(img, ref) and st.segments == ost.segments
-        images.append(img)
-    assert not np.array_equal(images[0], images[1])  # the winner really is the later one
-    # coincident spheres (all three kernels; the grid lists both in every cell they touch)
-    for order in ((0, 1), (1, 0)):
-        sc, keep = scene_of(cam, spheres=[(0, 0, 0, 0.8, order[0]), (0, 0, 0, 0.8, order[1]), (0, -100.8, 0, 100, 0)],
-                            materials=[red, blue])
-        ref, ost = orc.render(sc, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
-        img, st = device_images(ctx, sc, args)
-        assert np.array_equal(img, ref) and st.segments == ost.segments
+
+    def case(make, exact_kernels):
+        refs, bvh = [], []
+        for order in ((0, 1), (1, 0)):
+            sc, keep = make(order)
+            ref, ost = orc.render(sc, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
+            img, st = device_images(ctx, sc, args, kernels=exact_kernels)
+            assert np.array_equal(img, ref) and st.segments == ost.segments
+            for k in (rtow.KERNEL_BVH, rtow.KERNEL_BVH4):  # (BVH4 runs the binary walk when the scene has spheres)
+                b, bst = ctx.render(sc, rtow.make_config(*args, precision=rtow.F64_STRICT, kernel=k))
+                assert bst.segments == ost.segments
+                bvh.append(b)
+            refs.append(ref)
+        assert not np.array_equal(refs[0], refs[1])  # the winner really is the later one
+        for b in bvh:
+            assert np.array_equal(b, refs[0]) or np.array_equal(b, refs[1])
+
+    case(lambda o: scene_of(cam, triangles=[tri + (o[0],), tri + (o[1],)], materials=[red, blue]),
+         (rtow.KERNEL_BRUTE,))
+    # coincident spheres over a ground sphere (the grid lists both in every cell they touch)
+    case(lambda o: scene_of(cam, spheres=[(0, 0, 0, 0.8, o[0]), (0, 0, 0, 0.8, o[1]), (0, -100.8, 0, 100, 0)],
+                            materials=[red, blue]),
+         (rtow.KERNEL_BRUTE, rtow.KERNEL_GRID))
 
 
 def test_float_rounded_triangle_box_drops_a_stripe_in_the_reference(ctx):
@@ -152,7 +164,7 @@ def test_float_rounded_triangle_box_drops_a_stripe_in_the_reference(ctx):
     sc, keep = build(0.0)
     assert float(np.float32(X + 1)) == X  # the premise: 2^24 + 1 is not a float
     ref, ost = orc.render(sc, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
-    img, st = device_images(ctx, sc, args, kernels=(rtow.KERNEL_BRUTE, rtow.KERNEL_BVH))
+    img, st = device_images(ctx, sc, args, kernels=(rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_BVH4))
     assert st.segments > ost.segments  # the device also hits the stripe the reference's box cuts off
     # the difference is confined to the columns whose rays reach the triangle's plane at x > 2^24 (the
     # half-unit stripe right of the camera axis is ~3 pixels wide each way: columns 56..62 of 120);
@@ -161,5 +173,5 @@ def test_float_rounded_triangle_box_drops_a_stripe_in_the_reference(ctx):
     assert diff[56:63].any() and not diff[:55].any() and not diff[64:].any()
     sc1, keep1 = build(-1.0)
     ref1, ost1 = orc.render(sc1, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
-    img1, st1 = device_images(ctx, sc1, args, kernels=(rtow.KERNEL_BRUTE, rtow.KERNEL_BVH))
+    img1, st1 = device_images(ctx, sc1, args, kernels=(rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_BVH4))
     assert np.array_equal(img1, ref1) and st1.segments == ost1.segments

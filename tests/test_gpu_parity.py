@@ -37,7 +37,14 @@ def to8(img, spp):
     return (256 * np.clip(np.sqrt(img / spp), 0.0, 0.999)).astype(np.int32)
 
 
-KERNELS = {"stream": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID}
+KERNELS = {"stream": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID, "bvh4": rtow.KERNEL_BVH4}
+
+
+def expected_kernel(name, kernel):
+    """BVH4 is for triangle meshes; on scenes with spheres a BVH4 request runs the binary walk."""
+    if kernel == "bvh4" and name != "suzanne":
+        return rtow.KERNEL_BVH
+    return KERNELS[kernel]
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
@@ -48,7 +55,7 @@ def test_strict_is_bit_identical_to_oracle_and_golden(ctx, name, kernel):
     cfg = rtow.make_config(w, rtow.image_height(w, aspect), spp, ns, depth, seed=seed,
                            precision=rtow.F64_STRICT, kernel=KERNELS[kernel])
     img, st = ctx.render(scene, cfg)
-    assert st.kernel_used == KERNELS[kernel]
+    assert st.kernel_used == expected_kernel(name, kernel)
     ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
     assert img.shape == ref.shape
     assert np.array_equal(img, ref), f"{int((img != ref).sum())} of {img.size} values differ"
@@ -93,13 +100,14 @@ def test_bvh_and_stream_kernels_agree_bitwise(ctx, name):
     w = 320
     h = rtow.image_height(w, aspect)
     imgs = []
-    for k in (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_GRID):
+    kernels = [rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_GRID] + ([rtow.KERNEL_BVH4] if name == "suzanne" else [])
+    for k in kernels:
         cfg = rtow.make_config(w, h, 8, 2, depth, seed=seed + 100, precision=rtow.F64_STRICT, kernel=k)
         img, st = ctx.render(scene, cfg)
         assert st.kernel_used == k
         imgs.append((img, st.segments))
-    assert imgs[0][1] == imgs[1][1] == imgs[2][1]
-    assert np.array_equal(imgs[0][0], imgs[1][0]) and np.array_equal(imgs[0][0], imgs[2][0])
+    for img, segs in imgs[1:]:
+        assert segs == imgs[0][1] and np.array_equal(img, imgs[0][0])
 
 
 def test_mesh100k_global_image_path_is_bit_identical(ctx, tmp_path):
@@ -116,11 +124,15 @@ def test_mesh100k_global_image_path_is_bit_identical(ctx, tmp_path):
                    capture_output=True)
     scene = rtow.HostScene.obj(obj, 16 / 9)
     assert scene.c.n_triangles == 96800
-    cfg = rtow.make_config(96, 54, 2, 1, 20, seed=13, precision=rtow.F64_STRICT, kernel=rtow.KERNEL_BVH)
-    img, st = ctx.render(scene, cfg)
-    ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
-    assert st.segments == ost.segments
-    assert np.array_equal(img, ref), f"{int((img != ref).sum())} values differ"
+    ref = None
+    for kernel in (rtow.KERNEL_BVH, rtow.KERNEL_BVH4):  # binary walk over the global image; 4-wide walk, top of the tree in LDS
+        cfg = rtow.make_config(96, 54, 2, 1, 20, seed=13, precision=rtow.F64_STRICT, kernel=kernel)
+        img, st = ctx.render(scene, cfg)
+        assert st.kernel_used == kernel
+        if ref is None:
+            ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+        assert st.segments == ost.segments
+        assert np.array_equal(img, ref), f"{int((img != ref).sum())} values differ"
     # the same image from a subdivided mesh and from the original (same surface): statistically equal
     base = rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9)
     cfgf = rtow.make_config(96, 54, 16, 2, 20, seed=13, precision=rtow.F64_FAST)
@@ -232,7 +244,7 @@ def test_context_reuse_across_scenes_and_shapes(ctx):
     scenes = [
         (rtow.HostScene.cover(0, 1.5, False), 10, rtow.KERNEL_BRUTE),     # 4 primitives -> STREAM
         (rtow.HostScene.cover(11, 1.5, True), 50, rtow.KERNEL_GRID),      # spheres -> GRID
-        (rtow.HostScene.obj(GOLDEN / "suzanne.obj", 1.5), 20, rtow.KERNEL_BVH),  # mesh -> BVH
+        (rtow.HostScene.obj(GOLDEN / "suzanne.obj", 1.5), 20, rtow.KERNEL_BVH4),  # mesh -> 4-wide BVH
         (rtow.HostScene.cover(5, 1.5, False), 30, rtow.KERNEL_GRID),
     ]
     for (scene, depth, expect), (w, h, spp, ns) in zip(scenes, [(64, 40, 6, 3), (31, 17, 5, 1), (96, 64, 4, 2),
@@ -286,7 +298,7 @@ def test_large_strict_parity_all_kernels(ctx, name, w, spp):
     h = rtow.image_height(w, aspect)
     cfg0 = rtow.make_config(w, h, spp, 2, depth, seed=seed + 1000, precision=rtow.F64_STRICT)
     ref, ost = orc.render(scene, cfg0, orc.RNG_PHILOX, nthreads=16)
-    kernels = [rtow.KERNEL_BVH, rtow.KERNEL_GRID] + ([rtow.KERNEL_BRUTE] if name != "suzanne" else [])
+    kernels = [rtow.KERNEL_BVH, rtow.KERNEL_GRID] + ([rtow.KERNEL_BRUTE] if name != "suzanne" else [rtow.KERNEL_BVH4])
     for k in kernels:
         cfg = rtow.make_config(w, h, spp, 2, depth, seed=seed + 1000, precision=rtow.F64_STRICT, kernel=k)
         img, st = ctx.render(scene, cfg)
