@@ -191,6 +191,8 @@ struct Knobs {
   int sky_eighths = 1;            // RTOW_SKY_EIGHTHS
   bool stamps = false;            // RTOW_STAMPS: diagnostic region-stamp build
   bool no_bvh4 = false;           // RTOW_NO_BVH4: triangle meshes keep the binary threaded walk
+  bool bvh4_trips = false;        // RTOW_BVH4_TRIPS: the trip-structured BVH4 kernel instead of the state machine
+  int sm4_votes[3] = {8, 16, 16};  // RTOW_SM4_VOTES=restart,scatter,leaf: quorum of the state machine's blocks
   int bvh4_stack_k = 0;           // RTOW_BVH4_STACK_K: LDS stack entries per lane (0 = as many as fit, <= 32)
   void read() {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
@@ -210,6 +212,15 @@ struct Knobs {
     sky_eighths = std::min(std::max(geti("RTOW_SKY_EIGHTHS", 1), 0), 8);
     stamps = std::getenv("RTOW_STAMPS") != nullptr;
     no_bvh4 = std::getenv("RTOW_NO_BVH4") != nullptr;
+    bvh4_trips = std::getenv("RTOW_BVH4_TRIPS") != nullptr;
+    if (const char *e = std::getenv("RTOW_SM4_VOTES")) {
+      int a = 0, b = 0, d = 0;
+      if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
+        sm4_votes[0] = std::min(std::max(a, 1), 64);
+        sm4_votes[1] = std::min(std::max(b, 1), 64);
+        sm4_votes[2] = std::min(std::max(d, 1), 64);
+      }
+    }
     bvh4_stack_k = std::min(std::max(geti("RTOW_BVH4_STACK_K", 0), 0), 64);
   }
 };
@@ -909,6 +920,10 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
   P.spill = (uint32_t *)c->spill.p;
+  P.b4_trips = c->knobs.bvh4_trips ? 1u : 0u;
+  P.sm4_restart = (uint32_t)c->knobs.sm4_votes[0];
+  P.sm4_scatter = (uint32_t)c->knobs.sm4_votes[1];
+  P.sm4_leaf = (uint32_t)c->knobs.sm4_votes[2];
   P.counters = (unsigned long long *)c->counters.p;
   P.t_origin = P.counters + 16;
 

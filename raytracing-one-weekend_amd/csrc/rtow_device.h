@@ -97,6 +97,8 @@ struct TraceParams {
   double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   uint32_t *spill;         // BVH4 kernel: traversal stack entries beyond the LDS part, [entry][n_lanes]
+  uint32_t b4_trips;       // BVH4: 1 = the trip-structured kernel (rtow_trace_body.h) instead of the state machine
+  uint32_t sm4_restart, sm4_scatter, sm4_leaf;  // state machine: lanes that must wait for a block before it runs
   unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests
   unsigned long long *t_origin; // diagnostic build: earliest wave start (100 MHz clock)
 };

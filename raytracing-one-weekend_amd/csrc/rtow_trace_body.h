@@ -97,6 +97,181 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// ---- work items ------------------------------------------------------------------------------
+// A wave's share of the global item queue: one atomic buys a batch, lanes take items from the
+// wave-local pool [next, end) by ballot rank.  All fields are wave-uniform.
+struct ItemPool {
+  uint32_t next = 0, end = 0;
+  unsigned long long seen = 0ull;  // queue head as of this wave's last fetch
+};
+
+// Hands one queue position to every lane of `need_mask` (all lanes of the wave call this together).
+// Returns the lane's position, >= kp->n_items when the queue is exhausted.
+__device__ __forceinline__ unsigned long long take_items(ItemPool &pool, unsigned long long need_mask, unsigned lane,
+                                                         uint32_t n_waves, const RTOW_CONST TraceParams *kp,
+                                                         unsigned long long *counters) {
+  // Wave-local pool [next, end): one global atomic buys kItemBatch items, which the lanes then take by
+  // ballot rank with no further traffic (a single hot counter word saturates near 90 dequeues/us on this
+  // chip — one atomic per wave trip was the bottleneck).  All of this is wave-uniform except `mine`.
+  const uint32_t want = (uint32_t)__popcll(need_mask);
+  const uint32_t avail = pool.end - pool.next;
+  const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
+  unsigned long long mine = (unsigned long long)pool.next + rank;
+  if (want > avail) {
+    // guided self-scheduling: 64 items per atomic while the queue is long, shrinking to
+    // exactly what this wave needs now as it drains (a wave that hoards items at the end
+    // of the queue keeps the whole launch waiting: measured ~4 item durations per launch)
+    const unsigned long long left =
+        (unsigned long long)kp->n_items > pool.seen ? (unsigned long long)kp->n_items - pool.seen : 0ull;
+    uint32_t batch = (uint32_t)(left / ((unsigned long long)n_waves * 4ull));
+    batch = batch > kItemBatch ? kItemBatch : batch;
+    batch = batch < want - avail ? want - avail : batch;
+    const int leader = __ffsll((long long)need_mask) - 1;
+    unsigned long long base = pool.seen;
+    // a wave that has seen the end of the queue stops polling it: at the end of a launch every
+    // wave asks every trip, and the one counter word serves ~100 requests/us (measured: the
+    // last trips of a launch took 34 us instead of 13)
+    if (pool.seen < (unsigned long long)kp->n_items) {
+      if ((int)lane == leader) base = atomicAdd(&counters[0], (unsigned long long)batch);
+      base = __shfl(base, leader);
+    }
+    pool.seen = base + batch;  // how far the queue had advanced when this wave last looked
+    if (rank >= avail) mine = base + (rank - avail);
+    const unsigned long long nn = base + (want - avail), ne = base + batch;
+    const unsigned long long cap = (unsigned long long)kp->n_items;
+    pool.next = (uint32_t)(nn < cap ? nn : cap);
+    pool.end = (uint32_t)(ne < cap ? ne : cap);
+  } else {
+    pool.next += want;
+  }
+  return mine;
+}
+
+// Queue position -> (partial-sum slot, column, global row, first sample index).
+// Queue order.  Tiled mode: tile-major, stream-minor — all streams of a 64-pixel tile are
+// adjacent, tiles run top-to-bottom, and the queue is consumed from its far end, so a launch
+// ENDS on the top rows of the image for every stream.  In the reference's scenes that is sky
+// (the top 8 % of the cover image: one-segment paths), so most waves run out of work together:
+// waves finishing > 0.2 ms after they find the queue empty fell from 51 % to 5 % (+1.9 %).
+// (Stream-major order ended only the last stream on the sky; ending on the bottom rows —
+// near ground, short paths — measures the same.)  The partial-sum slot stays [stream][pixel].
+struct ItemPos {
+  uint32_t item, j, gi, sample0;
+};
+__device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp, uint32_t mine, uint32_t npix_local) {
+  ItemPos ip;
+  const uint32_t qi = kp->n_items - 1u - mine;
+  uint32_t k, lp, lr;
+  if (kp->tile_h_log2 == 0u) {  // row-major, stream-major
+    k = fastdiv(qi, FastDiv{kp->div_npix.magic, kp->div_npix.shift});
+    lp = qi - k * npix_local;
+    lr = fastdiv(lp, FastDiv{kp->div_w.magic, kp->div_w.shift});
+    ip.j = lp - lr * (uint32_t)kp->W;
+  } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile of one stream
+    const uint32_t g64 = qi >> 6, w = qi & 63u;
+    const uint32_t t = fastdiv(g64, FastDiv{kp->div_ns.magic, kp->div_ns.shift});
+    k = g64 - t * (uint32_t)kp->nstreams;
+    const uint32_t trq = fastdiv(t, FastDiv{kp->div_tpr.magic, kp->div_tpr.shift});  // tile row by queue position
+    const uint32_t tc = t - trq * (kp->div_tpr_n);
+    // Tile rows are consumed from the highest position down.  Positions >= sky_rows hold the
+    // rows below the top band, top-down (the horizon rows of an outdoor scene — its costliest —
+    // go first); the top band (sky_rows tile rows, typically one-segment paths) comes last.
+    const uint32_t tr = trq >= kp->sky_rows ? kp->sky_rows + (kp->n_tile_rows - 1u - trq) : trq;
+    lp = ((tr * kp->div_tpr_n + tc) << 6) | w;
+    lr = (tr << kp->tile_h_log2) + (w >> kp->tile_w_log2);
+    ip.j = (tc << kp->tile_w_log2) + (w & ((1u << kp->tile_w_log2) - 1u));
+  }
+  ip.item = k * npix_local + lp;  // partial-sum slot
+  // local row -> global row: this rank's q-th strip is global strip q*nranks+rank
+  const uint32_t q = fastdiv(lr, FastDiv{kp->div_tile.magic, kp->div_tile.shift});
+  const uint32_t rr = lr - q * (uint32_t)kp->tile_rows;
+  ip.gi = (q * (uint32_t)kp->nranks + (uint32_t)kp->rank) * (uint32_t)kp->tile_rows + rr;
+  ip.sample0 = (k + (uint32_t)kp->stream_first) * (uint32_t)kp->spt;  // first sample index of this stream
+  return ip;
+}
+
+// Camera::get_ray for sample (g.pixel, g.sample) of pixel (column j, global row gi): pixel jitter,
+// lens disk, ray (src/render.cpp:158-159, src/common-model.cpp:156-167; disk sample: y draws first,
+// random-utils.cpp:36).  The first lens candidate comes with the jitter block; every further block
+// carries two.
+__device__ __forceinline__ void camera_ray(const TraceParams &P, Rng &g, uint32_t k0, uint32_t k1, uint32_t j,
+                                           uint32_t gi, V3 &ro, V3 &rd, real &rtime) {
+  g.r = 0u;
+  const int from_top_i = P.H - (int)gi - 1;
+  real ju, jv, jt, c0, c1;
+  rng_jitter(g, k0, k1, ju, jv, jt, c0, c1);
+  const real u = fast_div((real)(int)j + ju, (real)(P.W - 1));
+  const real v = fast_div((real)from_top_i + jv, (real)(P.H - 1));
+  real py = c0 * (real(1.0) - real(-1.0)) + real(-1.0);
+  real px = c1 * (real(1.0) - real(-1.0)) + real(-1.0);
+  while (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) {
+    real a0, b0, a1, b1;
+    rng_disk2(g, k0, k1, a0, b0, a1, b1);
+    py = a0 * (real(1.0) - real(-1.0)) + real(-1.0);
+    px = b0 * (real(1.0) - real(-1.0)) + real(-1.0);
+    if (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) {
+      py = a1 * (real(1.0) - real(-1.0)) + real(-1.0);
+      px = b1 * (real(1.0) - real(-1.0)) + real(-1.0);
+    }
+  }
+  // camera block: wave-uniform scalar loads (origin u v horizontal vertical llc | lens t0 t1)
+#ifdef RTOW_REAL_F32
+  const RTOW_CONST float *cm = (const RTOW_CONST float *)P.cam32;
+#else
+  cdptr cm = (cdptr)(const double *)P.cam;
+#endif
+  const real lens = cm[18], ct0 = cm[19], ct1 = cm[20];
+  const real rdx = lens * px, rdy = lens * py;
+  const V3 offset = V3{cm[3], cm[4], cm[5]} * rdx + V3{cm[6], cm[7], cm[8]} * rdy;
+  const V3 from = V3{cm[0], cm[1], cm[2]} + offset;
+  rd = V3{cm[15], cm[16], cm[17]} + u * V3{cm[9], cm[10], cm[11]} + v * V3{cm[12], cm[13], cm[14]} - from;
+  ro = from;
+  rtime = jt * (ct1 - ct0) + ct0;
+}
+
+// Material::scatter (src/common-model.cpp:13-62) for a hit with shading normal `normal`: the new
+// direction, or absorbed.  The first unit-ball candidate of the bounce comes with the dielectric coin.
+__device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, int kind, real m_fuzz, real m_ir, V3 rd,
+                                            V3 normal, bool front, V3 &dir) {
+  real coin;
+  V3 rnd = rng_scatter(g, k0, k1, coin);
+  V3 dirbase = {0, 0, 0};
+  if (kind == 2) {
+    const real ir = m_ir;
+    const V3 unit = normalize(rd);
+    const real cos_theta = dot(-unit, normal);
+    const real sin_theta = fast_sqrt(real(1.0) - cos_theta * cos_theta);
+    const real ratio = front ? fast_rcp(ir) : ir;
+    bool refl = ratio * sin_theta > real(1.0);
+    if (!refl) {
+      real r0 = fast_div(real(1.0) - ratio, real(1.0) + ratio);
+      r0 = r0 * r0;
+      const real x = real(1.0) - cos_theta;
+      const real x2 = x * x;
+      const real R = r0 + (real(1.0) - r0) * (x2 * x2 * x);
+      refl = R > coin;
+    }
+    dirbase = refl ? reflect(unit, normal) : refract(unit, normal, ratio);
+  } else if (kind == 1) {
+    dirbase = reflect(rd, normal);
+  }
+  // random_unit_vector(): reject candidates outside the unit ball (random-utils.cpp:23-33)
+  while (dot(rnd, rnd) >= real(1.0)) {  // two candidates per further block
+    V3 ca, cb;
+    rng_scatter2(g, k0, k1, ca, cb);
+    rnd = dot(ca, ca) >= real(1.0) ? cb : ca;
+  }
+  bool absorbed = false;
+  if (kind == 0) {
+    absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
+               rabs(normal.z - rnd.z) < real(1e-8);
+    dir = normal + rnd;
+  } else {
+    dir = dirbase + m_fuzz * rnd;
+  }
+  return !absorbed;
+}
+
 // KERNEL: 1 = STREAM, 2 = BVH, 3 = GRID, 4 = BVH4;  LDS: scene image staged in LDS (2 and 3; the
 // BVH4 kernel always uses LDS: the image or its top, and the traversal stack)
 template <int KERNEL, bool LDS, bool STAMPS = false>
@@ -155,8 +330,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
                            // helper: its owner's lane id
   int n_out = 0;           // owner: donated samples not yet added
   uint32_t tail_trips = 0u;
-  uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: this wave's batch of work items
-  unsigned long long seen = 0ull;        // wave-uniform: queue head as of this wave's last fetch
+  ItemPool pool;  // wave-uniform: this wave's batch of work items
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   Stamps<STAMPS> stamps;
   stamps.start();
@@ -191,40 +365,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       // of SGPRs, so every one of them cost a v_readlane (VALU) per use.
       const RTOW_CONST TraceParams *kp = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(kp));  // opaque per trip: keeps the loads from being hoisted out of the loop
-      // Wave-local pool [pool_next, pool_end): one global atomic buys kItemBatch items,
-      // which the lanes then take by ballot rank with no further traffic (a single hot
-      // counter word saturates near 90 dequeues/us on this chip — one atomic per wave
-      // trip was the bottleneck).  All of this is wave-uniform except `mine`.
-      const uint32_t want = (uint32_t)__popcll(need_mask);
-      const uint32_t avail = pool_end - pool_next;
-      const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
-      unsigned long long mine = (unsigned long long)pool_next + rank;
-      if (want > avail) {
-        // guided self-scheduling: 64 items per atomic while the queue is long, shrinking to
-        // exactly what this wave needs now as it drains (a wave that hoards items at the end
-        // of the queue keeps the whole launch waiting: measured ~4 item durations per launch)
-        const unsigned long long left = (unsigned long long)kp->n_items > seen ? (unsigned long long)kp->n_items - seen : 0ull;
-        uint32_t batch = (uint32_t)(left / ((unsigned long long)n_waves * 4ull));
-        batch = batch > kItemBatch ? kItemBatch : batch;
-        batch = batch < want - avail ? want - avail : batch;
-        const int leader = __ffsll((long long)need_mask) - 1;
-        unsigned long long base = seen;
-        // a wave that has seen the end of the queue stops polling it: at the end of a launch every
-        // wave asks every trip, and the one counter word serves ~100 requests/us (measured: the
-        // last trips of a launch took 34 us instead of 13)
-        if (seen < (unsigned long long)kp->n_items) {
-          if ((int)lane == leader) base = atomicAdd(&P.counters[0], (unsigned long long)batch);
-          base = __shfl(base, leader);
-        }
-        seen = base + batch;  // how far the queue had advanced when this wave last looked
-        if (rank >= avail) mine = base + (rank - avail);
-        const unsigned long long nn = base + (want - avail), ne = base + batch;
-        const unsigned long long cap = (unsigned long long)kp->n_items;
-        pool_next = (uint32_t)(nn < cap ? nn : cap);
-        pool_end = (uint32_t)(ne < cap ? ne : cap);
-      } else {
-        pool_next += want;
-      }
+      const unsigned long long mine = take_items(pool, need_mask, lane, n_waves, kp, P.counters);
       if (need_item) {
         if (mine >= (unsigned long long)kp->n_items) {
           done = true;
@@ -232,41 +373,12 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             if (t_empty == 0ull) t_empty = __builtin_amdgcn_s_memrealtime();
           }
         } else {
-          // Queue order.  Tiled mode: tile-major, stream-minor — all streams of a 64-pixel tile are
-          // adjacent, tiles run top-to-bottom, and the queue is consumed from its far end, so a launch
-          // ENDS on the top rows of the image for every stream.  In the reference's scenes that is sky
-          // (the top 8 % of the cover image: one-segment paths), so most waves run out of work together:
-          // waves finishing > 0.2 ms after they find the queue empty fell from 51 % to 5 % (+1.9 %).
-          // (Stream-major order ended only the last stream on the sky; ending on the bottom rows —
-          // near ground, short paths — measures the same.)  The partial-sum slot stays [stream][pixel].
-          const uint32_t qi = kp->n_items - 1u - (uint32_t)mine;
-          uint32_t k, lp, lr;
-          if (kp->tile_h_log2 == 0u) {  // row-major, stream-major
-            k = fastdiv(qi, FastDiv{kp->div_npix.magic, kp->div_npix.shift});
-            lp = qi - k * npix_local;
-            lr = fastdiv(lp, FastDiv{kp->div_w.magic, kp->div_w.shift});
-            j = lp - lr * (uint32_t)kp->W;
-          } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile of one stream
-            const uint32_t g64 = qi >> 6, w = qi & 63u;
-            const uint32_t t = fastdiv(g64, FastDiv{kp->div_ns.magic, kp->div_ns.shift});
-            k = g64 - t * (uint32_t)kp->nstreams;
-            const uint32_t trq = fastdiv(t, FastDiv{kp->div_tpr.magic, kp->div_tpr.shift});  // tile row by queue position
-            const uint32_t tc = t - trq * (kp->div_tpr_n);
-            // Tile rows are consumed from the highest position down.  Positions >= sky_rows hold the
-            // rows below the top band, top-down (the horizon rows of an outdoor scene — its costliest —
-            // go first); the top band (sky_rows tile rows, typically one-segment paths) comes last.
-            const uint32_t tr = trq >= kp->sky_rows ? kp->sky_rows + (kp->n_tile_rows - 1u - trq) : trq;
-            lp = ((tr * kp->div_tpr_n + tc) << 6) | w;
-            lr = (tr << kp->tile_h_log2) + (w >> kp->tile_w_log2);
-            j = (tc << kp->tile_w_log2) + (w & ((1u << kp->tile_w_log2) - 1u));
-          }
-          item = k * npix_local + lp;  // partial-sum slot
-          // local row -> global row: this rank's q-th strip is global strip q*nranks+rank
-          const uint32_t q = fastdiv(lr, FastDiv{kp->div_tile.magic, kp->div_tile.shift});
-          const uint32_t rr = lr - q * (uint32_t)kp->tile_rows;
-          gi = (q * (uint32_t)kp->nranks + (uint32_t)kp->rank) * (uint32_t)kp->tile_rows + rr;
+          const ItemPos ip = decode_item(kp, (uint32_t)mine, npix_local);
+          item = ip.item;
+          j = ip.j;
+          gi = ip.gi;
           g.pixel = gi * (uint32_t)kp->W + j;
-          g.sample = (k + (uint32_t)kp->stream_first) * (uint32_t)kp->spt;  // first sample index of this stream
+          g.sample = ip.sample0;
           s_left = kp->spt;
           acc = {0.0, 0.0, 0.0};
         }
@@ -359,40 +471,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
 
     // ---- new sample: pixel jitter + Camera::get_ray ----------------------------
     if (live && need_sample) {
-      g.r = 0u;
-      // src/render.cpp:158-159
-      const int from_top_i = P.H - (int)gi - 1;
-      real ju, jv, jt, c0, c1;
-      rng_jitter(g, k0, k1, ju, jv, jt, c0, c1);
-      const real u = fast_div((real)(int)j + ju, (real)(P.W - 1));
-      const real v = fast_div((real)from_top_i + jv, (real)(P.H - 1));
-      // src/common-model.cpp:156-167; disk sample: y draws first (random-utils.cpp:36).  The first
-      // candidate came with the jitter block; every further block carries two.
-      real py = c0 * (real(1.0) - real(-1.0)) + real(-1.0);
-      real px = c1 * (real(1.0) - real(-1.0)) + real(-1.0);
-      while (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) {
-        real a0, b0, a1, b1;
-        rng_disk2(g, k0, k1, a0, b0, a1, b1);
-        py = a0 * (real(1.0) - real(-1.0)) + real(-1.0);
-        px = b0 * (real(1.0) - real(-1.0)) + real(-1.0);
-        if (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) {
-          py = a1 * (real(1.0) - real(-1.0)) + real(-1.0);
-          px = b1 * (real(1.0) - real(-1.0)) + real(-1.0);
-        }
-      }
-      // camera block: wave-uniform scalar loads (origin u v horizontal vertical llc | lens t0 t1)
-#ifdef RTOW_REAL_F32
-      const RTOW_CONST float *cm = (const RTOW_CONST float *)P.cam32;
-#else
-      cdptr cm = (cdptr)(const double *)P.cam;
-#endif
-      const real lens = cm[18], ct0 = cm[19], ct1 = cm[20];
-      const real rdx = lens * px, rdy = lens * py;
-      const V3 offset = V3{cm[3], cm[4], cm[5]} * rdx + V3{cm[6], cm[7], cm[8]} * rdy;
-      const V3 from = V3{cm[0], cm[1], cm[2]} + offset;
-      rd = V3{cm[15], cm[16], cm[17]} + u * V3{cm[9], cm[10], cm[11]} + v * V3{cm[12], cm[13], cm[14]} - from;
-      ro = from;
-      rtime = jt * (ct1 - ct0) + ct0;
+      camera_ray(P, g, k0, k1, j, gi, ro, rd, rtime);
       depth = P.max_child_rays;
       nb = 0;
 #ifdef RTOW_FAST_MATH
@@ -537,44 +616,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
           }
 
           // ---- Material::scatter (src/common-model.cpp:13-62) ------------------
-          // first unit-ball candidate of this bounce; its block also carries the coin
-          real coin;
-          V3 rnd = rng_scatter(g, k0, k1, coin);
-          V3 dirbase = {0, 0, 0};
-          if (kind == 2) {
-            const real ir = m_ir;
-            const V3 unit = normalize(rd);
-            const real cos_theta = dot(-unit, normal);
-            const real sin_theta = fast_sqrt(real(1.0) - cos_theta * cos_theta);
-            const real ratio = front ? fast_rcp(ir) : ir;
-            bool refl = ratio * sin_theta > real(1.0);
-            if (!refl) {
-              real r0 = fast_div(real(1.0) - ratio, real(1.0) + ratio);
-              r0 = r0 * r0;
-              const real x = real(1.0) - cos_theta;
-              const real x2 = x * x;
-              const real R = r0 + (real(1.0) - r0) * (x2 * x2 * x);
-              refl = R > coin;
-            }
-            dirbase = refl ? reflect(unit, normal) : refract(unit, normal, ratio);
-          } else if (kind == 1) {
-            dirbase = reflect(rd, normal);
-          }
-          // random_unit_vector(): reject candidates outside the unit ball (random-utils.cpp:23-33)
-          while (dot(rnd, rnd) >= real(1.0)) {  // two candidates per further block
-            V3 ca, cb;
-            rng_scatter2(g, k0, k1, ca, cb);
-            rnd = dot(ca, ca) >= real(1.0) ? cb : ca;
-          }
           V3 dir;
-          bool absorbed = false;
-          if (kind == 0) {
-            absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
-                       rabs(normal.z - rnd.z) < real(1e-8);
-            dir = normal + rnd;
-          } else {
-            dir = dirbase + m_fuzz * rnd;
-          }
+          const bool absorbed = !scatter_dir(g, k0, k1, kind, m_fuzz, m_ir, rd, normal, front, dir);
           if (absorbed) {
             need_sample = true;  // src/render.cpp:120: black
           } else {
@@ -679,9 +722,23 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   }
 }
 
+#include "rtow_trace_sm4.h"
+
 }  // namespace
 
-// kernel: 1 STREAM, 2 BVH, 3 GRID; +16 = diagnostic region stamps (LDS variants only)
+template <bool L, bool S>
+static int launch_sm4(const TraceParams &p, int grid, int block, unsigned lds_bytes, hipStream_t st) {
+  auto k = RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)<L, S>;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, st, p);
+  return (int)hipGetLastError();
+}
+
+// kernel: 1 STREAM, 2 BVH, 3 GRID, 4 BVH4; +16 = diagnostic region stamps (LDS variants only)
 template <int K, bool L, bool S>
 static int launch_one(const TraceParams &p, int grid, int block, unsigned lds_bytes, hipStream_t st) {
   auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<K, L, S>;
@@ -704,10 +761,19 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
                        : launch_one<2, false, false>(p, grid, block, 0, st);
     case 3: return lds ? launch_one<3, true, false>(p, grid, block, lds_bytes, st)
                        : launch_one<3, false, false>(p, grid, block, 0, st);
-    case 4: return p.sc.b4_lds_limit == p.sc.blob4_bytes ? launch_one<4, true, false>(p, grid, block, lds_bytes, st)
-                                                         : launch_one<4, false, false>(p, grid, block, lds_bytes, st);
-    case 4 + 16: return p.sc.b4_lds_limit == p.sc.blob4_bytes ? launch_one<4, true, true>(p, grid, block, lds_bytes, st)
-                                                              : launch_one<4, false, true>(p, grid, block, lds_bytes, st);
+    case 4:
+    case 4 + 16: {
+      const bool full = p.sc.b4_lds_limit == p.sc.blob4_bytes, stamps = kernel == 4 + 16;
+      if (p.b4_trips)  // the trip-structured form, kept for comparison (RTOW_BVH4_TRIPS)
+        return full ? (stamps ? launch_one<4, true, true>(p, grid, block, lds_bytes, st)
+                              : launch_one<4, true, false>(p, grid, block, lds_bytes, st))
+                    : (stamps ? launch_one<4, false, true>(p, grid, block, lds_bytes, st)
+                              : launch_one<4, false, false>(p, grid, block, lds_bytes, st));
+      return full ? (stamps ? launch_sm4<true, true>(p, grid, block, lds_bytes, st)
+                            : launch_sm4<true, false>(p, grid, block, lds_bytes, st))
+                  : (stamps ? launch_sm4<false, true>(p, grid, block, lds_bytes, st)
+                            : launch_sm4<false, false>(p, grid, block, lds_bytes, st));
+    }
     case 2 + 16: return launch_one<2, true, true>(p, grid, block, lds_bytes, st);
     case 3 + 16: return launch_one<3, true, true>(p, grid, block, lds_bytes, st);
     default: return (int)hipErrorInvalidValue;
