@@ -191,7 +191,13 @@ struct Knobs {
   int sky_eighths = 1;            // RTOW_SKY_EIGHTHS
   bool stamps = false;            // RTOW_STAMPS: diagnostic region-stamp build
   bool no_bvh4 = false;           // RTOW_NO_BVH4: triangle meshes keep the binary threaded walk
-  bool bvh4_trips = false;        // RTOW_BVH4_TRIPS: the trip-structured BVH4 kernel instead of the state machine
+  // Scheduling of the trip kernels (measured on one MI355X; 0 / "off" switches a measure off):
+  int fetch_votes = 4;            // RTOW_FETCH_VOTES: lanes that must need a work item before the fetch block runs
+  int leaf_votes = 0;             // RTOW_LEAF_VOTES: lanes that must hold a queued cell / leaf before a leaf phase
+                                  //   (0 = per kernel: GRID 16, BVH4 24)
+  int walk_cap = -1, walk_max_open = 0;  // RTOW_WALK_CAP=cap,max_open | off: resumable walk (-1 = per kernel:
+                                         //   GRID 3,16; BVH4 4,24 with the image in LDS, 4,40 otherwise)
+  bool bvh4_sm = false;           // RTOW_BVH4_SM: the state-machine form of the BVH4 kernel (rtow_trace_sm4.h)
   int sm4_votes[3] = {8, 16, 16};  // RTOW_SM4_VOTES=restart,scatter,leaf: quorum of the state machine's blocks
   int bvh4_stack_k = 0;           // RTOW_BVH4_STACK_K: LDS stack entries per lane (0 = as many as fit, <= 32)
   void read() {
@@ -212,7 +218,18 @@ struct Knobs {
     sky_eighths = std::min(std::max(geti("RTOW_SKY_EIGHTHS", 1), 0), 8);
     stamps = std::getenv("RTOW_STAMPS") != nullptr;
     no_bvh4 = std::getenv("RTOW_NO_BVH4") != nullptr;
-    bvh4_trips = std::getenv("RTOW_BVH4_TRIPS") != nullptr;
+    fetch_votes = std::min(std::max(geti("RTOW_FETCH_VOTES", 4), 1), 64);
+    leaf_votes = std::min(std::max(geti("RTOW_LEAF_VOTES", 0), 0), 64);
+    bvh4_sm = std::getenv("RTOW_BVH4_SM") != nullptr;
+    if (const char *e = std::getenv("RTOW_WALK_CAP")) {
+      int a = 0, b = 0;
+      if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) {
+        walk_cap = a;
+        walk_max_open = std::min(b, 64);
+      } else {
+        walk_cap = 0;  // "off"
+      }
+    }
     if (const char *e = std::getenv("RTOW_SM4_VOTES")) {
       int a = 0, b = 0, d = 0;
       if (std::sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) {
@@ -920,7 +937,20 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
   P.spill = (uint32_t *)c->spill.p;
-  P.b4_trips = c->knobs.bvh4_trips ? 1u : 0u;
+  P.b4_trips = c->knobs.bvh4_sm ? 0u : 1u;
+  {
+    const bool b4 = kernel == RTOW_KERNEL_BVH4;
+    const bool b4_full = b4 && scene.b4_lds_limit == scene.blob4_bytes;
+    int cap = c->knobs.walk_cap, open = c->knobs.walk_max_open;
+    if (cap < 0) {
+      cap = b4 ? 4 : 3;
+      open = b4 ? (b4_full ? 24 : 40) : 16;
+    }
+    P.walk_cap = cap > 0 ? (uint32_t)cap : 0xffffffffu;
+    P.walk_max_open = (uint32_t)open;
+    P.leaf_votes = (uint32_t)(c->knobs.leaf_votes > 0 ? c->knobs.leaf_votes : (b4 ? 24 : 16));
+  }
+  P.fetch_votes = (uint32_t)c->knobs.fetch_votes;
   P.sm4_restart = (uint32_t)c->knobs.sm4_votes[0];
   P.sm4_scatter = (uint32_t)c->knobs.sm4_votes[1];
   P.sm4_leaf = (uint32_t)c->knobs.sm4_votes[2];

@@ -97,7 +97,10 @@ struct TraceParams {
   double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   uint32_t *spill;         // BVH4 kernel: traversal stack entries beyond the LDS part, [entry][n_lanes]
-  uint32_t b4_trips;       // BVH4: 1 = the trip-structured kernel (rtow_trace_body.h) instead of the state machine
+  uint32_t b4_trips;       // BVH4: 1 = the trip-structured kernel (rtow_trace_body.h, default), 0 = the state machine
+  uint32_t fetch_votes;              // trip kernels: lanes that must need a new work item before the fetch block runs
+  uint32_t leaf_votes;               // GRID / BVH4 walks: lanes that must hold a queued cell / leaf before a leaf phase runs
+  uint32_t walk_cap, walk_max_open;  // GRID / BVH4 walks: resumable walk (rtow_trace_grid.h); cap 0xffffffff = never stop
   uint32_t sm4_restart, sm4_scatter, sm4_leaf;  // state machine: lanes that must wait for a block before it runs
   unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests
   unsigned long long *t_origin; // diagnostic build: earliest wave start (100 MHz clock)

@@ -323,6 +323,12 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
 #endif
   Rng g = {0, 0, 0};
   uint32_t nseg = 0, nnode = 0, nprim = 0;
+  // GRID kernel: a walk the wave stopped early continues in the next trip (rtow_trace_grid.h)
+  [[maybe_unused]] float t_resume = 0.0f;
+  [[maybe_unused]] uint32_t w_cur = 0x1fffffu, w_sa = 0u;  // BVH4: the same (kRefNone = no walk in progress)
+  Closest best;
+  best.t = 0;
+  best.prim = -1;
   // end-of-launch sample donation (see "tail" below)
   bool helping = false;    // this lane traces a sample donated by another lane of the wave
   bool holding = false;    // ... has finished it and keeps its colour in `acc` until the owner adds it
@@ -349,22 +355,30 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         holding = true;
         done = true;
       } else if (n_out == 0) {
-        if (item != 0xffffffffu) {
-          double *dst = P.partials + (size_t)item * 3;
-          dst[0] = acc.x;
-          dst[1] = acc.y;
-          dst[2] = acc.z;
-        }
         need_item = true;
       }  // else: an owner waiting for donated samples
     }
-    const unsigned long long need_mask = __ballot(need_item);
+    unsigned long long need_mask = __ballot(need_item);
+    // Lanes that need a new item wait until `fetch_votes` of them do (or nothing else is left to do): with
+    // 64 desynchronised lanes some lane finishes an item in almost every trip, and the fetch block — queue
+    // atomic, item decode, partial-sum store — would run every trip for two or three lanes.
+    if (need_mask != 0ull && (uint32_t)__popcll(need_mask) < P.fetch_votes && __ballot(!done && !need_item) != 0ull) {
+      need_mask = 0ull;
+      need_item = false;
+    }
     if (need_mask != 0ull) {
       // The item-decoding parameters are read here from the kernel-argument segment (scalar loads)
       // instead of living in SGPRs for the whole launch: the kernel is VALU-issue-bound and ran out
       // of SGPRs, so every one of them cost a v_readlane (VALU) per use.
       const RTOW_CONST TraceParams *kp = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(kp));  // opaque per trip: keeps the loads from being hoisted out of the loop
+      if (need_item && item != 0xffffffffu) {  // the finished item goes to its partial-sum slot
+        double *dst = P.partials + (size_t)item * 3;
+        dst[0] = acc.x;
+        dst[1] = acc.y;
+        dst[2] = acc.z;
+        item = 0xffffffffu;
+      }
       const unsigned long long mine = take_items(pool, need_mask, lane, n_waves, kp, P.counters);
       if (need_item) {
         if (mine >= (unsigned long long)kp->n_items) {
@@ -456,7 +470,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       }
       // structural bound on the tail (every wait above ends when a bounded path ends; this makes
       // the exit independent of that argument): give up donating, never hang
-      if (++tail_trips > 4096u + 8u * (uint32_t)(P.max_child_rays + 2) * (uint32_t)(P.spt + 1)) {
+      // (x64: a stopped-and-resumed walk spreads one segment over several trips)
+      if (++tail_trips > 64u * (4096u + 8u * (uint32_t)(P.max_child_rays + 2) * (uint32_t)(P.spt + 1))) {
         done = true;
         helping = false;
         holding = false;
@@ -486,13 +501,16 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       if (t_empty != 0ull) trips_after_empty += 1;
     }
     // ---- one ray segment: closest hit --------------------------------------------
-    Closest best;
-    best.t = 0;
-    best.prim = -1;
+    if constexpr (KERNEL != 3 && KERNEL != 4) {
+      best.t = 0;
+      best.prim = -1;
+    }
     if constexpr (KERNEL == 4) {
-      best = closest_hit_bvh4<LDS, STAMPS>(im4, sc, P, ro, rd, rtime, live, lane_g, nnode, nprim, stamps);
+      best = closest_hit_bvh4<LDS, STAMPS>(im4, sc, P, ro, rd, rtime, live, lane_g, nnode, nprim, stamps, best, w_cur, w_sa,
+                                           P.walk_cap, P.walk_max_open);
     } else if constexpr (KERNEL == 3) {
-      best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
+      best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps, best, t_resume, P.walk_cap,
+                                           P.walk_max_open, P.leaf_votes);
     } else if constexpr (KERNEL == 2) {
       // the walk uses wave votes, so every lane of the wave enters it
       best = closest_hit_bvh<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
@@ -501,7 +519,10 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     }
 
     stamps.mark(RG_WALK);
-    if (live) {
+    bool arrived = live;  // the segment's closest hit is known (a stopped GRID walk continues next trip)
+    if constexpr (KERNEL == 3) arrived = live && !(t_resume > 0.0f);
+    if constexpr (KERNEL == 4) arrived = live && w_cur == 0x1fffffu;
+    if (arrived) {
       ++nseg;
       if (best.prim >= 0) {
         if (depth <= 0) {
@@ -764,7 +785,7 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
     case 4:
     case 4 + 16: {
       const bool full = p.sc.b4_lds_limit == p.sc.blob4_bytes, stamps = kernel == 4 + 16;
-      if (p.b4_trips)  // the trip-structured form, kept for comparison (RTOW_BVH4_TRIPS)
+      if (p.b4_trips)  // the trip-structured form (default); RTOW_BVH4_SM selects the state machine
         return full ? (stamps ? launch_one<4, true, true>(p, grid, block, lds_bytes, st)
                               : launch_one<4, true, false>(p, grid, block, lds_bytes, st))
                     : (stamps ? launch_one<4, false, true>(p, grid, block, lds_bytes, st)

@@ -62,13 +62,20 @@ struct Bvh4Reader {
   __device__ __forceinline__ uint32_t u32(uint32_t off) const { return rec<uint32_t>(off); }
 };
 
+// Resumable like the grid walk (rtow_trace_grid.h): after `cap` loop trips with at most `max_open`
+// lanes still walking, the queued leaves are tested and the unfinished lanes keep their place — the
+// node in hand (`w_cur`, kRefNone = no walk in progress), the stack (it lives in LDS / the spill
+// array; `w_sa` is its top) and the closest hit so far — for the caller's next trip.
 template <bool FULL, bool ST>
 __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, const DevScene &sc, const TraceParams &P,
                                                     V3 o, V3 d, real time, bool active, uint32_t lane_g, uint32_t &nnode,
-                                                    uint32_t &nprim, Stamps<ST> &stamps) {
-  Closest best;
-  best.t = (real)__builtin_huge_val();
-  best.prim = -1;
+                                                    uint32_t &nprim, Stamps<ST> &stamps, Closest best, uint32_t &w_cur,
+                                                    uint32_t &w_sa, uint32_t cap, uint32_t max_open) {
+  const bool resumed = w_cur != kRefNone;
+  if (!resumed) {
+    best.t = (real)__builtin_huge_val();
+    best.prim = -1;
+  }
   const RayForms ray = make_ray_forms(o, d, time);
   const float tmin32 = 0.0009f;   // < RTOW_TMIN
   const float slack = 1.00002f;   // relative slack on the far side of the interval, folded into the far-plane terms
@@ -76,8 +83,8 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
   const float oix = (float)o.x * ix, oiy = (float)o.y * iy, oiz = (float)o.z * iz;
   const float jx = ix * slack, jy = iy * slack, jz = iz * slack;
   const float ojx = oix * slack, ojy = oiy * slack, ojz = oiz * slack;
-  float tmax32 = __builtin_huge_valf();  // closest hit so far, rounded up
-  float tfm = __builtin_huge_valf();     // ... times slack
+  float tmax32 = round_up_f32(best.t);  // closest hit so far, rounded up
+  float tfm = tmax32 * slack;           // ... times slack
   // where this ray finds the near planes of a node (the far planes are at the same address ^ 16)
   const uint32_t nxo = ix < 0.0f ? 16u : 0u, nyo = iy < 0.0f ? 48u : 32u, nzo = iz < 0.0f ? 80u : 64u;
   // the stack: LDS slot s of this lane at stack_lds + s * kStride (workgroups are 1024 lanes); `sa` is the
@@ -85,9 +92,10 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
   constexpr uint32_t kStrideLog2 = 12u, kStride = 1u << kStrideLog2;
   const uint32_t stack_lds = sc.b4_stack_base + 4u * threadIdx.x;
   const uint32_t sa_end = stack_lds + (sc.b4_stack_k << kStrideLog2);
-  uint32_t sa = stack_lds;
-  uint32_t cur = active ? 0u : kRefNone;  // node 0 = root
+  uint32_t sa = resumed ? w_sa : stack_lds;
+  uint32_t cur = !active ? kRefNone : (resumed ? w_cur : 0u);  // node 0 = root
   uint32_t q0 = kRefNone, q1 = kRefNone;  // queued leaves, oldest first
+  uint32_t trips = 0u;                    // wave-uniform
 
   for (;;) {
     if constexpr (ST) stamps.iters += 1;
@@ -159,8 +167,16 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
       RTOW_PUSH(3, cw.w)
 #undef RTOW_PUSH
     }
-    const bool any_walking = __any(cur != kRefNone);
-    if (__any(q1 != kRefNone) || !any_walking) {
+    const unsigned long long m_walking = __ballot(cur != kRefNone);
+    const bool any_walking = m_walking != 0ull;
+    ++trips;
+    const bool suspend = any_walking && trips >= cap && (uint32_t)__popcll(m_walking) <= max_open;
+    // leaf phase: when enough lanes hold a queued leaf, or when no lane can take a node step (every
+    // walking lane holds a leaf it cannot queue), or at the end
+    const bool busy = cur != kRefNone && !((cur & kRefLeaf) != 0u && cur < kRefPop && q1 != kRefNone);
+    const unsigned long long m_pending = __ballot(q0 != kRefNone);
+    if ((m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= P.leaf_votes || __ballot(busy) == 0ull)) || !any_walking ||
+        suspend) {
       stamps.mark(RG_WALK);
       if constexpr (ST) stamps.phases += 1;
       // leaf phase: every lane tests the triangles of the OLDEST leaf it queued
@@ -177,11 +193,29 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
       }
       q0 = q1;
       q1 = kRefNone;
+      if (suspend && q0 != kRefNone) {  // both queued leaves before stopping
+        const uint32_t first = (q0 & (kRefLeaf - 1u)) >> 2, count = (q0 & 3u) + 1u;
+        for (uint32_t k = 0; k < count; ++k) {
+          const uint32_t r = sc.b4_off_tri + 96u * (first + k);
+          const vd2 t0 = im.d2(r), t1 = im.d2(r + 16u), t2 = im.d2(r + 32u), t3 = im.d2(r + 48u), t4 = im.d2(r + 64u),
+                    t5 = im.d2(r + 80u);
+          ++nprim;
+          triangle_test<double>(ray.o64, ray.d64, V3d{t0.x, t0.y, t1.x}, V3d{t1.y, t2.x, t2.y}, V3d{t3.x, t3.y, t4.x},
+                                V3d{t4.y, t5.x, t5.y}, (int)(first + k), RTOW_TMIN, best);
+        }
+        q0 = kRefNone;
+      }
       tmax32 = round_up_f32(best.t);  // rounded up: never below the f64 value
       tfm = tmax32 * slack;
       stamps.mark(RG_LEAF);
+      if (suspend) {
+        w_cur = cur;  // kRefNone for the lanes that are done
+        w_sa = sa;
+        return best;
+      }
       if (!any_walking && !__any(q0 != kRefNone)) break;
     }
   }
+  w_cur = kRefNone;
   return best;
 }

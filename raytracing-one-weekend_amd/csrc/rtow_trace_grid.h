@@ -8,13 +8,26 @@
 // the SIMT-dense leaf phase.  The walk ends when the ray leaves the grid (integer cell
 // counters, so at most nx+ny+nz steps whatever the floats do) or when the exit distance of
 // the current cell is beyond the closest hit so far.
+//
+// Resumable walk.  A wave's walk lasts as long as its slowest lane — typically one or two rays that
+// graze the ground and cross ten cells while the others need one or two.  When the walk has run
+// `cap` loop trips and at most `max_open` lanes are still walking, it stops: the queued cells are
+// tested, and every lane that is not finished remembers where it stands — the closest hit so far
+// (`best`) and the ray parameter at which it entered its current cell (`t_resume` > 0).  The caller
+// shades the finished lanes as usual and calls again in its next trip; a resumed lane skips the
+// large-primitive list and re-enters the grid at t_resume (a hair earlier: the cell containing that
+// point or its predecessor, so no cell is skipped; a cell tested twice changes nothing).
 template <bool LDS, bool ST>
 __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const DevScene &sc, V3 o,
                                                     V3 d, real time, bool active, uint32_t &nnode,
-                                                    uint32_t &nprim, Stamps<ST> &stamps) {
-  Closest best;
-  best.t = (real)__builtin_huge_val();
-  best.prim = -1;
+                                                    uint32_t &nprim, Stamps<ST> &stamps, Closest best,
+                                                    float &t_resume, uint32_t cap, uint32_t max_open,
+                                                    uint32_t leaf_votes) {
+  const bool resumed = t_resume > 0.0f;
+  if (!resumed) {
+    best.t = (real)__builtin_huge_val();
+    best.prim = -1;
+  }
   const RayForms ray = make_ray_forms(o, d, time);
   ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri, 0u, sc.g_off_sph32, sc.g_off_mov32};
   int last_id = -1;
@@ -31,7 +44,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   // the large primitives, for every ray.  Static spheres are taken four (then two) at a time:
   // all records are loaded and all discriminants computed before any hit branch, so LDS
   // latency and the f64 dependency chains of one test overlap the others.
-  if (active && n_large != 0u) {
+  if (active && !resumed && n_large != 0u) {
     const uint32_t lf = (off_large - off.ids) >> 2;
     uint32_t k = 0;
     for (; k + 3 < n_large; k += 4) {
@@ -83,7 +96,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   const float ax = fmaf(gx, ix, -oix), bx = fmaf(hx, ix, -oix);
   const float ay = fmaf(gy, iy, -oiy), by = fmaf(hy, iy, -oiy);
   const float az = fmaf(gz, iz, -oiz), bz = fmaf(hz, iz, -oiz);
-  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0009f));
+  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), fmaxf(0.0009f, t_resume * 0.999999f)));
   const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax32));
   bool walking = active && t0 <= t1 * 1.00002f;
 
@@ -103,9 +116,11 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   int idx = (c2 * ny + c1) * nx + c0;
 
   uint32_t q0 = 0u, q1 = 0u;
+  float t_entry = t0;  // ray parameter at which the lane entered its current cell
+  uint32_t trips = 0u;  // wave-uniform
   for (;;) {
     if constexpr (ST) stamps.iters += 1;
-    if (walking) {
+    if (walking && q1 == 0u) {  // (a lane with two cells queued waits for the next leaf phase)
       const uint32_t cw = im.u32(sc.g_off_cells + 4u * (uint32_t)idx);
       ++nnode;
       if (cw != 0u) {
@@ -120,6 +135,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
       const float tnext = sx ? tmx : (sy ? tmy : tmz);
       const int rem = sx ? remx : (sy ? remy : remz);
       walking = rem > 0 && !(tnext > tmax32);
+      t_entry = tnext;
       idx += sx ? incx : (sy ? incy : incz);
       tmx += sx ? tdx : 0.0f;
       tmy += sy ? tdy : 0.0f;
@@ -128,18 +144,35 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
       remy -= sy ? 1 : 0;
       remz -= (!sx && !sy) ? 1 : 0;
     }
-    const bool any_walking = __any(walking);
-    if (__any(q1 != 0u) || !any_walking) {
+    const unsigned long long m_walking = __ballot(walking);
+    const bool any_walking = m_walking != 0ull;
+    ++trips;
+    // stop here and resume in the caller's next trip?  (never on the first trips: most lanes finish there)
+    const bool suspend = any_walking && trips >= cap && (uint32_t)__popcll(m_walking) <= max_open;
+    // leaf phase: when `leaf_votes` lanes hold a queued cell, when no lane can take a step, or at the end
+    const unsigned long long m_pending = __ballot(q0 != 0u);
+    if ((m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= leaf_votes || __ballot(walking && q1 == 0u) == 0ull)) ||
+        !any_walking || suspend) {
       stamps.mark(RG_WALK);
       if constexpr (ST) stamps.phases += 1;
       if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
       q0 = q1;
       q1 = 0u;
+      if (suspend && __any(q0 != 0u)) {  // both queued cells before stopping
+        if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
+        q0 = 0u;
+      }
       tmax32 = round_up_f32(best.t);
       stamps.mark(RG_LEAF);
+      if (suspend) {
+        // a lane whose next cell starts beyond the hit it has just found is finished after all
+        t_resume = (walking && !(t_entry > tmax32)) ? t_entry : 0.0f;
+        return best;
+      }
       if (!any_walking && !__any(q0 != 0u)) break;
     }
   }
+  t_resume = 0.0f;
   return best;
 }
 
