@@ -199,7 +199,8 @@ struct Knobs {
                                          //   GRID 3,16; BVH4 4,24 with the image in LDS, 4,40 otherwise)
   bool bvh4_sm = false;           // RTOW_BVH4_SM: the state-machine form of the BVH4 kernel (rtow_trace_sm4.h)
   int sm4_votes[3] = {8, 16, 16};  // RTOW_SM4_VOTES=restart,scatter,leaf: quorum of the state machine's blocks
-  int bvh4_stack_k = 0;           // RTOW_BVH4_STACK_K: LDS stack entries per lane (0 = as many as fit, <= 32)
+  int bvh4_stack_k = 0;           // RTOW_BVH4_STACK_K: image staged whole if this many stack entries per lane still fit
+                                  //   (default 8), else the entries per lane beside the staged top of the tree (default 24)
   void read() {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
     auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
@@ -832,16 +833,13 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
     const uint32_t per_entry = 4u * (uint32_t)block;
     stack_bound = 3 * c->bvh4_depth + 1;
     uint32_t K, staged;
-    if (scene.blob4_bytes + 8u * per_entry <= kLdsLimit) {
+    const uint32_t min_k = c->knobs.bvh4_stack_k > 0 ? (uint32_t)c->knobs.bvh4_stack_k : 8u;  // RTOW_BVH4_STACK_K
+    if (scene.blob4_bytes + min_k * per_entry <= kLdsLimit) {
       staged = scene.blob4_bytes;
       K = std::min<uint32_t>((kLdsLimit - staged) / per_entry, 32u);
     } else {
-      K = 24u;
+      K = c->knobs.bvh4_stack_k > 0 ? std::min<uint32_t>((uint32_t)c->knobs.bvh4_stack_k, 32u) : 24u;
       staged = std::min<uint32_t>((kLdsLimit - K * per_entry) / 128u * 128u, scene.b4_off_tri);
-    }
-    if (c->knobs.bvh4_stack_k > 0 && (uint32_t)c->knobs.bvh4_stack_k * per_entry + (staged == scene.blob4_bytes ? staged : 0u) <= kLdsLimit) {
-      K = (uint32_t)c->knobs.bvh4_stack_k;
-      if (staged != scene.blob4_bytes) staged = std::min<uint32_t>((kLdsLimit - K * per_entry) / 128u * 128u, scene.b4_off_tri);
     }
     K = std::min<uint32_t>(K, (uint32_t)stack_bound);
     scene.b4_lds_limit = staged;

@@ -9,7 +9,7 @@ ARGS="--workload $WL --no-other-configs --no-end-to-end $*"
 mkdir -p gpurun_out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/stats_$TAG -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-scaling-base $ARGS > gpurun_out/stats_$TAG.log 2>&1 || { echo "stats run failed"; tail -5 gpurun_out/stats_$TAG.log; exit 1; }
 cp $(ls gpurun_out/stats_$TAG/*/*kernel_stats.csv | head -1) gpurun_out/${TAG}_kernel_stats.csv
-tail -1 gpurun_out/stats_$TAG.log > gpurun_out/${TAG}_bench.json
+grep "^{\"metric\"" gpurun_out/stats_$TAG.log | tail -1 > gpurun_out/${TAG}_bench.json
 bash scripts/pmc_passes.sh $TAG $ARGS || exit 1
 python3 scripts/pmc_summary.py $TAG rtow_trace $WL fast $KU > gpurun_out/${TAG}_pmc.json
 echo "profiled $WL -> gpurun_out/${TAG}_{kernel_stats.csv,bench.json,pmc.json}"
