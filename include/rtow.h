@@ -258,6 +258,17 @@ int rtow_render(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *c
 int rtow_render_rgb8(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,
                      unsigned char *rgb8_host, rtow_stats_t *stats);
 
+/* One frame over several HIP devices from ONE process (replaces the reference's thread fan-out and
+ * in-order sum, src/render.cpp:169-180): one host thread + context per entry of `device_ids`, strips of
+ * cfg->tile_rows rows dealt round-robin (cfg->rank / nranks are ignored: rank = position in the list),
+ * then with use_rccl != 0 ONE ncclGather (RCCL over xGMI; librccl.so is loaded on demand) of the strip
+ * buffers to the first device and ONE device-to-host copy, with use_rccl == 0 one copy per device.
+ * `rgb_sums_host`: image_height*image_width*3 doubles, row-major from the top, the radiance sums of
+ * the whole frame — identical, bit for bit, to a one-device rtow_render of the same config.  RCCL rejects
+ * a device listed twice; use_rccl == 0 accepts it (tests of the partition on a one-GPU machine). */
+int rtow_render_multi(int32_t n_devices, const int32_t *device_ids, const rtow_scene_t *scene,
+                      const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats, int32_t use_rccl);
+
 /* ---- host-side scene construction (no GPU needed) --------------------------
  * C entry points over the C++ mirror of the reference's scene-build API
  * (host/scene.h ≙ src/common-model.h, src/oo-primitives.h, src/render.h):

@@ -38,6 +38,21 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
+}  // namespace
+namespace rtow {
+// for the other translation units of the library (rtow_multi.cpp): same thread-local message
+int set_last_error(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace rtow
+namespace {
+
 #define HIPCHK(expr)                                                                       \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \

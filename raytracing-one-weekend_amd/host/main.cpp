@@ -34,7 +34,9 @@ static void usage(const char *argv0) {
                "  --builder host|device       BVH build: host SAH (default) or on the GPU (LBVH)\n"
                "  --p6                        binary P6 output, write_color on the device\n"
                "  --general-obj               with -l: load every shape, not only the first\n"
-               "  --gpus INT                  tile-split over INT devices (--device is the first)\n";
+               "  --gpus INT                  tile-split over INT devices (--device is the first), strips gathered\n"
+               "                              to the first device with one ncclGather (RCCL)\n"
+               "  --rccl                      take the RCCL gather path even with one device\n";
 }
 
 int main(int argc, char *argv[]) {
@@ -94,6 +96,8 @@ int main(int argc, char *argv[]) {
         if (opt.gpus < 1 || opt.gpus > 64) throw std::runtime_error("--gpus: 1..64");
       } else if (std::strcmp(a, "--gpus-same-device") == 0) {  // test hook: every rank on --device
         opt.gpus_same_device = true;
+      } else if (std::strcmp(a, "--rccl") == 0) {  // gather through RCCL even with one device
+        opt.rccl = true;
       } else if (std::strcmp(a, "--builder") == 0) {
         const std::string v = value();
         if (v == "host") opt.builder = 0;

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <iostream>
 #include <stdexcept>
@@ -13,6 +14,8 @@
 #include <thread>
 #include <unordered_map>
 #include <vector>
+
+#include <unistd.h>
 
 #include "../../include/rtow.h"
 
@@ -226,60 +229,53 @@ void render(const Scene &world, const Config &cfg) {
   rtow_build_info_t bi;
   std::memset(&bi, 0, sizeof bi);
   const int ngpus = std::max(opt.gpus, 1);
-  std::vector<int> errs(ngpus, RTOW_OK);
-  std::vector<std::string> msgs(ngpus);
-  std::vector<rtow_stats_t> stats(ngpus);
-  std::vector<rtow_build_info_t> infos(ngpus);
-  // one rank = one device = one host thread; rank r owns the strips r, r+N, r+2N, ...
-  auto run_rank = [&](int rank) {
-    rtow_config_t mine = rc;
-    mine.rank = rank;
-    mine.nranks = ngpus;
-    rtow_ctx *ctx = nullptr;
-    int err = rtow_ctx_create(opt.gpus_same_device ? opt.device : opt.device + rank, &ctx);
-    if (err == RTOW_OK && opt.builder >= 0) err = rtow_ctx_set_builder(ctx, opt.builder);
-    const int rows = rtow_local_rows(&mine);
-    std::vector<int32_t> row_ids((size_t)std::max(rows, 0));
-    if (err == RTOW_OK && rows > 0) (void)rtow_local_row_list(&mine, row_ids.data(), rows);
-    const size_t row_values = (size_t)cfg.image_width * 3;
-    std::vector<double> part(opt.binary_ppm ? 0 : row_values * (size_t)std::max(rows, 0));
-    std::vector<unsigned char> part8(opt.binary_ppm ? row_values * (size_t)std::max(rows, 0) : 0);
-    std::memset(&stats[rank], 0, sizeof(rtow_stats_t));
-    if (err == RTOW_OK)
-      err = opt.binary_ppm ? rtow_render_rgb8(ctx, flat_view(flat), &mine, part8.data(), &stats[rank])
-                           : rtow_render(ctx, flat_view(flat), &mine, part.data(), &stats[rank]);
-    if (err == RTOW_OK) {
-      (void)rtow_build_info(ctx, &infos[rank]);
-      for (int i = 0; i < rows; ++i) {  // this rank's rows, ascending, into their global places
-        if (opt.binary_ppm)
-          std::memcpy(rgb8.data() + (size_t)row_ids[i] * row_values, part8.data() + (size_t)i * row_values, row_values);
-        else
-          std::memcpy(image.data() + (size_t)row_ids[i] * row_values, part.data() + (size_t)i * row_values,
-                      row_values * sizeof(double));
+  const int spp_eff_all = cfg.samples_per_pixel / cfg.nthreads * cfg.nthreads;
+  if (ngpus > 1 || opt.rccl) {
+    // several devices (or --rccl): rtow_render_multi — one host thread and context per device, strips dealt
+    // round-robin, one ncclGather to the first device + one D2H (distinct devices), or one D2H per rank
+    // (--gpus-same-device: RCCL cannot span a device twice)
+    std::vector<int32_t> devs((size_t)ngpus);
+    for (int r = 0; r < ngpus; ++r) devs[(size_t)r] = opt.gpus_same_device ? opt.device : opt.device + r;
+    std::vector<double> sums(nvalues);
+    const int use_rccl = opt.gpus_same_device && ngpus > 1 ? 0 : 1;
+    if (opt.builder >= 0) setenv("RTOW_BUILDER", opt.builder == RTOW_BUILDER_DEVICE_LBVH ? "device" : "host", 1);
+    // RCCL prints a version banner on stdout when it initialises; stdout is the PPM (src/render.cpp:182-186),
+    // so the banner is sent to stderr for the duration of the call
+    std::cout.flush();
+    std::fflush(stdout);
+    const int saved_stdout = dup(1);
+    if (saved_stdout >= 0) (void)dup2(2, 1);
+    const int err = nvalues ? rtow_render_multi(ngpus, devs.data(), flat_view(flat), &rc, sums.data(), &st, use_rccl) : RTOW_OK;
+    std::fflush(stdout);
+    if (saved_stdout >= 0) {
+      (void)dup2(saved_stdout, 1);
+      close(saved_stdout);
+    }
+    flat_free(flat);
+    if (err != RTOW_OK)
+      throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + rtow_last_error());
+    if (opt.binary_ppm) {  // write_color on the host: the same correctly rounded operations as the device epilogue
+      for (size_t q = 0; q < nvalues; ++q) {
+        double c = std::sqrt(sums[q] / static_cast<double>(spp_eff_all));
+        c = c < 0.0 ? 0.0 : (c > 0.999 ? 0.999 : c);
+        const int v = static_cast<int>(256.0 * c);
+        rgb8[q] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
       }
     } else {
-      msgs[rank] = rtow_last_error();  // thread-local text of this rank's failure
+      image.swap(sums);
     }
-    errs[rank] = err;
-    rtow_ctx_destroy(ctx);
-  };
-  if (ngpus == 1) {
-    run_rank(0);
   } else {
-    std::vector<std::thread> workers;
-    for (int r = 0; r < ngpus; ++r) workers.emplace_back(run_rank, r);
-    for (auto &w : workers) w.join();
-  }
-  flat_free(flat);
-  for (int r = 0; r < ngpus; ++r)
-    if (errs[r] != RTOW_OK)
-      throw std::runtime_error("HIP render failed on rank " + std::to_string(r) + " (" + std::to_string(errs[r]) +
-                               "): " + msgs[r]);
-  bi = infos[0];
-  for (int r = 0; r < ngpus; ++r) {
-    st.samples += stats[r].samples;
-    st.segments += stats[r].segments;
-    st.kernel_ms = std::max(st.kernel_ms, stats[r].kernel_ms);
+    rtow_ctx *ctx = nullptr;
+    int err = rtow_ctx_create(opt.device, &ctx);
+    if (err == RTOW_OK && opt.builder >= 0) err = rtow_ctx_set_builder(ctx, opt.builder);
+    if (err == RTOW_OK && nvalues)
+      err = opt.binary_ppm ? rtow_render_rgb8(ctx, flat_view(flat), &rc, rgb8.data(), &st)
+                           : rtow_render(ctx, flat_view(flat), &rc, image.data(), &st);
+    const std::string msg = err == RTOW_OK ? std::string() : std::string(rtow_last_error());
+    if (err == RTOW_OK && nvalues) (void)rtow_build_info(ctx, &bi);
+    rtow_ctx_destroy(ctx);
+    flat_free(flat);
+    if (err != RTOW_OK) throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + msg);
   }
 
   const int spp_eff = cfg.samples_per_pixel / cfg.nthreads * cfg.nthreads;  // src/render.cpp:185

@@ -34,12 +34,15 @@ struct DeviceOptions {
   // OBJ input beyond the reference's (which reads shapes[0] only and throws on a face that is not a
   // triangle, src/main.cpp:115-133): every shape of the file, polygons fan-triangulated
   bool general_obj = false;
-  // --gpus N: strips of 8 rows dealt round-robin to devices device .. device+N-1, one host thread
-  // and one context per device, rows copied straight into the host image (the PPM needs it on the
-  // host anyway; bench.py is the one-process-per-GPU + RCCL form).  gpus_same_device: all N
-  // contexts on `device` (tests the partition on a one-GPU box).
+  // --gpus N: strips of 8 rows dealt round-robin to devices device .. device+N-1, one host thread and one
+  // context per device (rtow_render_multi): ONE ncclGather of the strip buffers to the first device, one
+  // device-to-host copy (bench.py is the one-process-per-GPU form of the same partition).
+  // gpus_same_device: all N contexts on `device`, every rank copies its own strips to the host — RCCL
+  // cannot span one device twice; this tests the partition on a one-GPU box.  rccl: take the RCCL path
+  // even with one device (a one-rank communicator; exercises the collective where only one GPU exists).
   int gpus = 1;
   bool gpus_same_device = false;
+  bool rccl = false;
 };
 DeviceOptions &device_options();
 

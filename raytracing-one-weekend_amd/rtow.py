@@ -100,7 +100,7 @@ EXPORTS = [
     "rtow_render", "rtow_host_scene_cover", "rtow_host_scene_obj", "rtow_host_scene_free",
     "rtow_host_rng_reset", "rtow_host_ppm", "rtow_host_free", "rtow_tonemap_device",
     "rtow_profile_collect", "rtow_debug_counters", "rtow_render_rgb8",
-    "rtow_ctx_set_builder", "rtow_build_info", "rtow_debug_image",
+    "rtow_ctx_set_builder", "rtow_build_info", "rtow_debug_image", "rtow_render_multi",
 ]
 
 
@@ -153,6 +153,8 @@ def lib():
     L.rtow_tonemap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     L.rtow_ctx_set_builder.argtypes = [C.c_void_p, C.c_int32]
     L.rtow_build_info.argtypes = [C.c_void_p, C.POINTER(BuildInfo)]
+    L.rtow_render_multi.argtypes = [C.c_int32, _pi, C.POINTER(Scene), C.POINTER(Config), _pd, C.POINTER(Stats),
+                                    C.c_int32]
     L.rtow_debug_image.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     if L.rtow_abi_version() != RTOW_ABI_VERSION:
         raise RtowError("librtow.so ABI version mismatch")
@@ -321,6 +323,19 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def render_multi(device_ids, scene, cfg: Config, use_rccl=True):
+    """One frame over several devices from this process (rtow_render_multi): returns ([H, W, 3] sums, Stats)."""
+    import numpy as np
+
+    s = scene.c if isinstance(scene, HostScene) else scene
+    ids = (C.c_int32 * len(device_ids))(*device_ids)
+    out = np.zeros((cfg.image_height, cfg.image_width, 3), dtype=np.float64)
+    st = Stats()
+    check(lib().rtow_render_multi(len(device_ids), ids, C.byref(s), C.byref(cfg), out.ctypes.data_as(_pd), C.byref(st),
+                                  int(bool(use_rccl))), "rtow_render_multi")
+    return out, st
 
 
 def have_gpu() -> bool:

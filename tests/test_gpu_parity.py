@@ -508,6 +508,38 @@ def test_rtweekend_gpus_flag_partitions_like_one_device(ctx):
     assert bad.returncode != 0
 
 
+def test_rtweekend_rccl_path_with_one_rank(ctx):
+    """rtow_render_multi (the single-process multi-device form): with use_rccl the strips go through a
+    real RCCL communicator (ncclCommInitAll, one ncclGather, one D2H).  A one-GPU box can only hold a
+    one-rank communicator, so this checks that path end to end with N = 1 — library loaded on demand,
+    communicator, collective, copy, reassembly — and the N = 3 partition without the collective; the
+    frames equal the single-context frame bit for bit.  (N > 1 over RCCL needs N devices: unmeasured.)"""
+    import subprocess
+
+    from conftest import REPO
+
+    scene = rtow.HostScene.cover(11, 1.5, True)
+    cfg = rtow.make_config(150, 100, 12, 3, 30, seed=9, precision=rtow.F64_STRICT, tile_rows=8)
+    whole, st = ctx.render(scene, cfg)
+    one, s1 = rtow.render_multi([0], scene, cfg, use_rccl=True)
+    assert np.array_equal(one, whole) and s1.segments == st.segments and s1.samples == st.samples
+    three, s3 = rtow.render_multi([0, 0, 0], scene, cfg, use_rccl=False)
+    assert np.array_equal(three, whole) and s3.segments == st.segments
+    L = rtow.lib()
+    ids = (C.c_int32 * 2)(0, 0)
+    out = np.zeros((100, 150, 3))
+    rc = L.rtow_render_multi(2, ids, C.byref(scene.c), C.byref(cfg), out.ctypes.data_as(C.POINTER(C.c_double)), None, 1)
+    assert rc != 0  # RCCL refuses a communicator over the same device twice: an error, not a wrong image
+    exe = REPO / "raytracing-one-weekend_amd" / "rtweekend"
+    base = [str(exe), "-w", "96", "-a", "1.5", "-s", "8", "-c", "20", "-t", "2", "--precision", "strict"]
+    plain = subprocess.run(base, capture_output=True, check=True)
+    rccl = subprocess.run(base + ["--rccl"], capture_output=True, check=True)
+    assert rccl.stdout == plain.stdout
+    p6 = subprocess.run(base + ["--p6"], capture_output=True, check=True)
+    p6r = subprocess.run(base + ["--p6", "--rccl"], capture_output=True, check=True)
+    assert p6r.stdout == p6.stdout
+
+
 def test_fast_and_f32_builds_are_run_to_run_deterministic(ctx):
     """The image must not depend on which lane traced which sample: work is handed out dynamically and
     idle lanes take over samples at the end of a launch, so e.g. a multiply fused into the pixel
