@@ -495,20 +495,35 @@ def main():
             # build of the acceleration structure), kernels, D2H of the f64 sums into caller memory
             import numpy as np
 
+            import ctypes as C2
+
             host = np.zeros((H, W, 3), dtype=np.float64)
-            ctx.render(scene, cfg, into=None)
-            t1 = time.perf_counter()
+            host8 = np.zeros((H, W, 3), dtype=np.uint8)
+            L = rtow.lib()
+            L.rtow_render_rgb8.argtypes = [C2.c_void_p, C2.POINTER(rtow.Scene), C2.POINTER(rtow.Config), C2.c_void_p,
+                                           C2.POINTER(rtow.Stats)]
             n_e2e = 3
-            for _ in range(n_e2e):
-                host, est = ctx.render(scene, cfg)
-            e1 = (time.perf_counter() - t1) / n_e2e
+
+            def timed(fn):
+                fn()
+                t1 = time.perf_counter()
+                for _ in range(n_e2e):
+                    fn()
+                return (time.perf_counter() - t1) / n_e2e
+
+            e1 = timed(lambda: ctx.render(scene, cfg, into=host))
+            e8 = timed(lambda: rtow.check(L.rtow_render_rgb8(ctx._h, C2.byref(scene.c), C2.byref(cfg),
+                                                             host8.ctypes.data_as(C2.c_void_p), None), "rtow_render_rgb8"))
             bi = ctx.build_info()
             out["end_to_end"] = {
                 "value": round(W * H * spp_eff / e1 / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(e1 * 1e3, 4),
                 "calls": n_e2e, "upload_ms": round(bi.upload_ms, 3),
                 "build_ms": round(bi.bvh_build_ms + bi.grid_build_ms, 3),
                 "region": "rtow_render(): scene upload + acceleration build + trace + reduce + D2H of W*H*3 f64 sums "
-                          "into caller memory (SURVEY.md §8d; `value` above excludes upload and D2H)",
+                          "into caller memory (SURVEY.md §8d; `value` at the top excludes upload and D2H)",
+                "rgb8": {"value": round(W * H * spp_eff / e8 / 1e6, 3), "ms_per_call": round(e8 * 1e3, 4),
+                         "region": "rtow_render_rgb8(): the same with write_color on the device and W*H*3 BYTES to the "
+                                   "host — the values the reference prints into its PPM (src/render.cpp:11-20,182-186)"},
             }
         if world == 1 and a.workload == "cover" and spp == 100 and not a.no_scaling_base:
             # like-for-like base of the N>1 lines (configs[2], 500 spp): the same frame on this one

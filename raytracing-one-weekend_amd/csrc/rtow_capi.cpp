@@ -283,6 +283,7 @@ struct rtow_ctx {
   rtow_build_info_t build_info{};
   // workspace
   DevBuf partials, stack, counters, spill;
+  DevBuf out, out8;  // rtow_render / rtow_render_rgb8: device-side output of the host-buffer entry points
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
   int occ[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
@@ -337,7 +338,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
-                    &c->partials, &c->stack, &c->counters, &c->spill})
+                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8})
     b->release();
   for (int i = 0; i < kEventRing; ++i)
     for (int k = 0; k < 2; ++k)
@@ -1104,21 +1105,12 @@ int rtow_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg
     }
     return RTOW_OK;
   }
-  void *d_out = nullptr;
-  HIPCHK(hipMalloc(&d_out, bytes));
-  if (cfg->accumulate) {  // continue from the caller's sums
-    hipError_t e0 = hipMemcpy(d_out, rgb_sums_host, bytes, hipMemcpyHostToDevice);
-    if (e0 != hipSuccess) {
-      (void)hipFree(d_out);
-      return fail(RTOW_EHIP, "H2D copy failed: %s", hipGetErrorString(e0));
-    }
-  }
+  if ((rc = c->out.ensure(bytes))) return rc;  // kept across calls
+  void *d_out = c->out.p;
+  if (cfg->accumulate)  // continue from the caller's sums
+    HIPCHK(hipMemcpy(d_out, rgb_sums_host, bytes, hipMemcpyHostToDevice));
   rc = rtow_render_device(c, cfg, d_out, nullptr, stats ? stats : &local);
-  if (rc == RTOW_OK) {
-    hipError_t e = hipMemcpy(rgb_sums_host, d_out, bytes, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(RTOW_EHIP, "D2H copy failed: %s", hipGetErrorString(e));
-  }
-  (void)hipFree(d_out);
+  if (rc == RTOW_OK) HIPCHK(hipMemcpy(rgb_sums_host, d_out, bytes, hipMemcpyDeviceToHost));
   return rc;
 }
 
@@ -1141,21 +1133,10 @@ int rtow_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t
     if (stats) std::memset(stats, 0, sizeof *stats);
     return RTOW_OK;
   }
-  void *d_sums = nullptr, *d_rgb8 = nullptr;
-  HIPCHK(hipMalloc(&d_sums, n * sizeof(double)));
-  hipError_t e = hipMalloc(&d_rgb8, n);
-  if (e != hipSuccess) {
-    (void)hipFree(d_sums);
-    return fail(RTOW_EHIP, "hipMalloc: %s", hipGetErrorString(e));
-  }
-  rc = rtow_render_device(c, cfg, d_sums, nullptr, stats ? stats : &local);
-  if (rc == RTOW_OK) rc = rtow_tonemap_device(c, d_sums, (int64_t)n, spp_eff, d_rgb8, nullptr);
-  if (rc == RTOW_OK) {
-    e = hipMemcpy(rgb8_host, d_rgb8, n, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) rc = fail(RTOW_EHIP, "D2H copy failed: %s", hipGetErrorString(e));
-  }
-  (void)hipFree(d_sums);
-  (void)hipFree(d_rgb8);
+  if ((rc = c->out.ensure(n * sizeof(double))) || (rc = c->out8.ensure(n))) return rc;  // kept across calls
+  rc = rtow_render_device(c, cfg, c->out.p, nullptr, stats ? stats : &local);
+  if (rc == RTOW_OK) rc = rtow_tonemap_device(c, c->out.p, (int64_t)n, spp_eff, c->out8.p, nullptr);
+  if (rc == RTOW_OK) HIPCHK(hipMemcpy(rgb8_host, c->out8.p, n, hipMemcpyDeviceToHost));
   return rc;
 }
 
