@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   // per-lane state
   bool done = false;
   bool need_sample = true;
+  bool pending_hit = false;   // the last segment ended in a hit that is scattered at the top of the next trip
   int s_left = 0;             // samples left in the current item
   uint32_t item = 0xffffffffu;
   uint32_t j = 0;             // column
@@ -484,9 +485,221 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     // (a lane whose fresh item has no samples — spt == 0 — goes straight back for the next one)
     const bool live = !done && !(need_sample && s_left <= 0);
 
-    // ---- new sample: pixel jitter + Camera::get_ray ----------------------------
-    if (live && need_sample) {
-      camera_ray(P, g, k0, k1, j, gi, ro, rd, rtime);
+    // ---- new rays ------------------------------------------------------------------------------------
+    // Two kinds of lanes need a new ray before the walk: those starting a sample (pixel jitter +
+    // Camera::get_ray, src/render.cpp:158-159, src/common-model.cpp:156-167) and those whose previous
+    // segment ended in a hit (Material::scatter, src/common-model.cpp:13-62).  Both draw one Philox
+    // block and then, while their candidate lies outside the unit disk / unit ball, further blocks.
+    // They draw TOGETHER: one block evaluation serves both kinds of lanes, and the rejection loop runs
+    // max(lens, ball) trips instead of lens + ball — a wave used to spend ~6 block evaluations per trip on
+    // ~1.4 needed per lane.  Every lane still consumes exactly its own requests in its own order
+    // (counter = (request, sample, pixel)), so nothing changes in the image.
+    const bool do_regen = live && need_sample;
+    const bool do_scat = live && pending_hit;
+    V3 where = {0, 0, 0}, normal = {0, 0, 0};
+    bool front = true;
+    int mi = 0, kind = 0;
+    real m_fuzz = 0, m_ir = 0;
+#ifdef RTOW_FAST_MATH
+    V3 m_att = {1, 1, 1};
+#endif
+    if (do_scat) {
+      // rebuild the Hit of the winner (src/common-model.cpp:83-90, :121).  The walking
+      // kernels read the winner's record, its material index and the material from the
+      // LDS scene image (a chain of three dependent loads: LDS latency, not L2's)
+      where = ro + rd * best.t;
+      const int pid = best.prim;
+      if constexpr (KERNEL == 4) {
+        // triangles only: the un-normalised normal e1 x e2 of the record (src/common-model.cpp:121)
+        const uint32_t r = sc.b4_off_tri + 96u * (uint32_t)pid;
+        const vd2 q4 = im4.d2(r + 64u), q5 = im4.d2(r + 80u);
+        normal = {(real)q4.y, (real)q5.x, (real)q5.y};
+        mi = (int)im4.u32(sc.b4_off_pmat + 4u * (uint32_t)pid);
+        const uint32_t mr = sc.b4_off_mats + 48u * (uint32_t)mi;
+        const vd2 m1 = im4.d2(mr + 16u), m2 = im4.d2(mr + 32u);  // {att.z, fuzz}, {ir, kind|pad}
+#ifdef RTOW_FAST_MATH
+        const vd2 m0 = im4.d2(mr);  // {att.x, att.y}
+        m_att = V3{(real)m0.x, (real)m0.y, (real)m1.x};
+#endif
+        m_fuzz = (real)m1.y;
+        m_ir = (real)m2.x;
+        kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
+      } else if constexpr (KERNEL >= 2) {
+        const uint32_t o_sph = KERNEL == 3 ? sc.g_off_sph : sc.off_sph;
+        const uint32_t o_mov = KERNEL == 3 ? sc.g_off_mov : sc.off_mov;
+        const uint32_t o_tri = KERNEL == 3 ? sc.g_off_tri : sc.off_tri;
+        const uint32_t o_pmat = KERNEL == 3 ? sc.g_off_pmat : sc.off_pmat;
+        const uint32_t o_mats = KERNEL == 3 ? sc.g_off_mats : sc.off_mats;
+        if (pid < sc.n_sph + sc.n_mov) {
+          V3 center;
+          bool inward;  // negative radius: only the sign of the signed r*r is used here
+          if (pid < sc.n_sph) {
+            const double2 p0 = im.d2(o_sph + 32u * (uint32_t)pid), p1 = im.d2(o_sph + 32u * (uint32_t)pid + 16u);
+            center = {(real)p0.x, (real)p0.y, (real)p1.x};
+            inward = p1.y < 0.0;
+          } else {
+            const uint32_t r = o_mov + 64u * (uint32_t)(pid - sc.n_sph);
+            const double2 p0 = im.d2(r), p1 = im.d2(r + 16u), p2 = im.d2(r + 32u), p3 = im.d2(r + 48u);
+#ifdef RTOW_REAL_F32
+            center = {(real)p0.x + rtime * (real)p1.y, (real)p0.y + rtime * (real)p2.x, (real)p1.x + rtime * (real)p2.y};
+#else
+            center = {p0.x + rtime * p1.y, p0.y + rtime * p2.x, p1.x + rtime * p2.y};
+#endif
+            inward = p3.x < 0.0;
+          }
+          normal = normalize(where - center);
+          front = (dot(rd, normal) < real(0.0)) ^ inward;
+          normal = front ? normal : -normal;
+        } else {
+#ifdef RTOW_REAL_F32
+          const uint32_t r = o_tri + 48u * (uint32_t)(pid - sc.n_sph - sc.n_mov);
+          const float4 q2 = im.f4(r + 32u);
+          normal = {q2.y, q2.z, q2.w};
+#else
+          const uint32_t r = o_tri + 96u * (uint32_t)(pid - sc.n_sph - sc.n_mov);
+          const double2 q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
+          normal = {q4.y, q5.x, q5.y};
+#endif
+        }
+        mi = (int)im.u32(o_pmat + 4u * (uint32_t)pid);
+        const uint32_t mr = o_mats + 48u * (uint32_t)mi;
+        const double2 m1 = im.d2(mr + 16u), m2 = im.d2(mr + 32u);  // {att.z, fuzz}, {ir, kind|pad}
+#ifdef RTOW_FAST_MATH
+        const double2 m0 = im.d2(mr);  // {att.x, att.y}
+        m_att = V3{(real)m0.x, (real)m0.y, (real)m1.x};
+#endif
+        m_fuzz = (real)m1.y;
+        m_ir = (real)m2.x;
+        kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
+      } else {
+        if (pid < sc.n_sph + sc.n_mov) {
+          V3 center;
+          bool inward;
+          if (pid < sc.n_sph) {
+            const double *q = sc.sph + 4 * (size_t)pid;
+            center = {(real)q[0], (real)q[1], (real)q[2]};
+            inward = sc.sph_r[pid] < 0.0;
+          } else {
+            const double *q = sc.mov + 8 * (size_t)(pid - sc.n_sph);
+#ifdef RTOW_REAL_F32
+            center = {(real)q[0] + rtime * (real)q[3], (real)q[1] + rtime * (real)q[4], (real)q[2] + rtime * (real)q[5]};
+#else
+            center = {q[0] + rtime * q[3], q[1] + rtime * q[4], q[2] + rtime * q[5]};
+#endif
+            inward = q[7] < 0.0;
+          }
+          normal = normalize(where - center);
+          front = (dot(rd, normal) < real(0.0)) ^ inward;
+          normal = front ? normal : -normal;
+        } else {
+          const double *q = sc.tri + 12 * (size_t)(pid - sc.n_sph - sc.n_mov);
+          normal = {(real)q[9], (real)q[10], (real)q[11]};
+        }
+        mi = sc.prim_mat[pid];
+        const DevMaterial *m = sc.mats + mi;
+#ifdef RTOW_FAST_MATH
+        m_att = V3{(real)m->att[0], (real)m->att[1], (real)m->att[2]};
+#endif
+        kind = m->kind;
+        m_fuzz = (real)m->fuzz;
+        m_ir = (real)m->ir;
+      }
+
+    }
+    // first block of the sample / of the bounce
+    uint32_t o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u;
+    if (do_regen) g.r = 0u;
+    if (do_regen || do_scat) {
+      philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+      g.r += 1u;
+    }
+#ifdef RTOW_EXTRA_PHILOX  // timing experiment only: what one more block evaluation per trip costs
+    if (do_regen || do_scat) {
+      uint32_t x0, x1, x2, x3;
+      philox4x32(g.r + 77u, g.sample, g.pixel, 1u, k0, k1, x0, x1, x2, x3);
+      if (x0 == 0x12345678u && x1 == 0x9abcdefu && x2 == x3) o0 ^= 1u;
+    }
+#endif
+    if constexpr (STAMPS) {  // wave-level count of block evaluations: the first active lane reports
+      if ((do_regen || do_scat) && (int)lane == __ffsll((long long)__ballot(do_regen || do_scat)) - 1)
+        atomicAdd(&P.counters[44], 1ull);
+    }
+    real ju = 0, jv = 0, jt = 0, px = 0, py = 0;  // new sample: jitter, shutter time, lens-disk candidate
+    V3 rnd = {0, 0, 0}, dirbase = {0, 0, 0};      // bounce: unit-ball candidate, direction before the fuzz term
+    bool rej = false;
+    if (do_regen) {
+      // disk sample: y draws first (random-utils.cpp:36).  The first candidate comes with the jitter block.
+      real c0, c1;
+      jitter_from_block(o0, o1, o2, o3, ju, jv, jt, c0, c1);
+      py = c0 * (real(1.0) - real(-1.0)) + real(-1.0);
+      px = c1 * (real(1.0) - real(-1.0)) + real(-1.0);
+      rej = px * px + py * py + real(0.0) * real(0.0) >= real(1.0);
+    }
+    if (do_scat) {
+      // the first unit-ball candidate of the bounce comes with the dielectric coin (word 2)
+      const real coin = (real)o2 * real(0x1p-32);
+      rnd = ball_from_pair(o0, o1);
+      if (kind == 2) {
+        const real ir = m_ir;
+        const V3 unit = normalize(rd);
+        const real cos_theta = dot(-unit, normal);
+        const real sin_theta = fast_sqrt(real(1.0) - cos_theta * cos_theta);
+        const real ratio = front ? fast_rcp(ir) : ir;
+        bool refl = ratio * sin_theta > real(1.0);
+        if (!refl) {
+          real r0 = fast_div(real(1.0) - ratio, real(1.0) + ratio);
+          r0 = r0 * r0;
+          const real x = real(1.0) - cos_theta;
+          const real x2 = x * x;
+          const real R = r0 + (real(1.0) - r0) * (x2 * x2 * x);
+          refl = R > coin;
+        }
+        dirbase = refl ? reflect(unit, normal) : refract(unit, normal, ratio);
+      } else if (kind == 1) {
+        dirbase = reflect(rd, normal);
+      }
+      rej = dot(rnd, rnd) >= real(1.0);
+    }
+    // rejection sampling (random-utils.cpp:23-41): every further block carries two candidates
+    while (rej) {
+      if constexpr (STAMPS) {
+        if ((int)lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&P.counters[44], 1ull);
+      }
+      philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+      g.r += 1u;
+      if (do_regen) {
+        const real s32 = real(0x1p-32);
+        py = ((real)o0 * s32) * (real(1.0) - real(-1.0)) + real(-1.0);
+        px = ((real)o1 * s32) * (real(1.0) - real(-1.0)) + real(-1.0);
+        if (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) {
+          py = ((real)o2 * s32) * (real(1.0) - real(-1.0)) + real(-1.0);
+          px = ((real)o3 * s32) * (real(1.0) - real(-1.0)) + real(-1.0);
+        }
+        rej = px * px + py * py + real(0.0) * real(0.0) >= real(1.0);
+      } else {
+        const V3 ca = ball_from_pair(o0, o1), cb = ball_from_pair(o2, o3);
+        rnd = dot(ca, ca) >= real(1.0) ? cb : ca;
+        rej = dot(rnd, rnd) >= real(1.0);
+      }
+    }
+    if (do_regen) {
+      // src/render.cpp:158-159, src/common-model.cpp:156-167
+      const int from_top_i = P.H - (int)gi - 1;
+      const real u = fast_div((real)(int)j + ju, (real)(P.W - 1));
+      const real v = fast_div((real)from_top_i + jv, (real)(P.H - 1));
+      // camera block: wave-uniform scalar loads (origin u v horizontal vertical llc | lens t0 t1)
+#ifdef RTOW_REAL_F32
+      const RTOW_CONST float *cm = (const RTOW_CONST float *)P.cam32;
+#else
+      cdptr cm = (cdptr)(const double *)P.cam;
+#endif
+      const real lens = cm[18], ct0 = cm[19], ct1 = cm[20];
+      const real rdx = lens * px, rdy = lens * py;
+      const V3 offset = V3{cm[3], cm[4], cm[5]} * rdx + V3{cm[6], cm[7], cm[8]} * rdy;
+      const V3 from = V3{cm[0], cm[1], cm[2]} + offset;
+      rd = V3{cm[15], cm[16], cm[17]} + u * V3{cm[9], cm[10], cm[11]} + v * V3{cm[12], cm[13], cm[14]} - from;
+      ro = from;
+      rtime = jt * (ct1 - ct0) + ct0;
       depth = P.max_child_rays;
       nb = 0;
 #ifdef RTOW_FAST_MATH
@@ -494,6 +707,34 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
 #endif
       need_sample = false;
     }
+    if (do_scat) {
+      pending_hit = false;
+      bool absorbed = false;
+      V3 dir;
+      if (kind == 0) {
+        absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
+                   rabs(normal.z - rnd.z) < real(1e-8);
+        dir = normal + rnd;
+      } else {
+        dir = dirbase + m_fuzz * rnd;
+      }
+      if (absorbed) {
+        need_sample = true;  // src/render.cpp:120: black (the lane starts its next sample in the next trip)
+        --s_left;
+        ++g.sample;
+      } else {
+#ifdef RTOW_FAST_MATH
+        throughput = throughput * m_att;
+#else
+        P.stack[(size_t)nb * P.n_lanes + lane_g] = (uint32_t)mi;
+#endif
+        ++nb;
+        --depth;
+        ro = where;
+        rd = dir;
+      }
+    }
+    const bool tracing = live && !need_sample;  // has a ray to advance in this trip
 
     stamps.mark(RG_REGEN);
     if constexpr (STAMPS) {
@@ -506,153 +747,29 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       best.prim = -1;
     }
     if constexpr (KERNEL == 4) {
-      best = closest_hit_bvh4<LDS, STAMPS>(im4, sc, P, ro, rd, rtime, live, lane_g, nnode, nprim, stamps, best, w_cur, w_sa,
+      best = closest_hit_bvh4<LDS, STAMPS>(im4, sc, P, ro, rd, rtime, tracing, lane_g, nnode, nprim, stamps, best, w_cur, w_sa,
                                            P.walk_cap, P.walk_max_open);
     } else if constexpr (KERNEL == 3) {
-      best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps, best, t_resume, P.walk_cap,
+      best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, tracing, nnode, nprim, stamps, best, t_resume, P.walk_cap,
                                            P.walk_max_open, P.leaf_votes);
     } else if constexpr (KERNEL == 2) {
       // the walk uses wave votes, so every lane of the wave enters it
-      best = closest_hit_bvh<LDS, STAMPS>(im, sc, ro, rd, rtime, live, nnode, nprim, stamps);
+      best = closest_hit_bvh<LDS, STAMPS>(im, sc, ro, rd, rtime, tracing, nnode, nprim, stamps);
     } else {
-      if (live) best = closest_hit_stream(sc, to_f64(ro), to_f64(rd), (double)rtime);
+      if (tracing) best = closest_hit_stream(sc, to_f64(ro), to_f64(rd), (double)rtime);
     }
 
     stamps.mark(RG_WALK);
-    bool arrived = live;  // the segment's closest hit is known (a stopped GRID walk continues next trip)
-    if constexpr (KERNEL == 3) arrived = live && !(t_resume > 0.0f);
-    if constexpr (KERNEL == 4) arrived = live && w_cur == 0x1fffffu;
+    bool arrived = tracing;  // the segment's closest hit is known (a stopped GRID / BVH4 walk continues next trip)
+    if constexpr (KERNEL == 3) arrived = tracing && !(t_resume > 0.0f);
+    if constexpr (KERNEL == 4) arrived = tracing && w_cur == 0x1fffffu;
     if (arrived) {
       ++nseg;
       if (best.prim >= 0) {
-        if (depth <= 0) {
+        if (depth <= 0)
           need_sample = true;  // src/render.cpp:115: black
-        } else {
-          // rebuild the Hit of the winner (src/common-model.cpp:83-90, :121).  The walking
-          // kernels read the winner's record, its material index and the material from the
-          // LDS scene image (a chain of three dependent loads: LDS latency, not L2's)
-          V3 where = ro + rd * best.t;
-          V3 normal;
-          bool front = true;
-          const int pid = best.prim;
-          int mi, kind;
-          real m_fuzz, m_ir;
-#ifdef RTOW_FAST_MATH
-          V3 m_att;
-#endif
-          if constexpr (KERNEL == 4) {
-            // triangles only: the un-normalised normal e1 x e2 of the record (src/common-model.cpp:121)
-            const uint32_t r = sc.b4_off_tri + 96u * (uint32_t)pid;
-            const vd2 q4 = im4.d2(r + 64u), q5 = im4.d2(r + 80u);
-            normal = {(real)q4.y, (real)q5.x, (real)q5.y};
-            mi = (int)im4.u32(sc.b4_off_pmat + 4u * (uint32_t)pid);
-            const uint32_t mr = sc.b4_off_mats + 48u * (uint32_t)mi;
-            const vd2 m1 = im4.d2(mr + 16u), m2 = im4.d2(mr + 32u);  // {att.z, fuzz}, {ir, kind|pad}
-#ifdef RTOW_FAST_MATH
-            const vd2 m0 = im4.d2(mr);  // {att.x, att.y}
-            m_att = V3{(real)m0.x, (real)m0.y, (real)m1.x};
-#endif
-            m_fuzz = (real)m1.y;
-            m_ir = (real)m2.x;
-            kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
-          } else if constexpr (KERNEL >= 2) {
-            const uint32_t o_sph = KERNEL == 3 ? sc.g_off_sph : sc.off_sph;
-            const uint32_t o_mov = KERNEL == 3 ? sc.g_off_mov : sc.off_mov;
-            const uint32_t o_tri = KERNEL == 3 ? sc.g_off_tri : sc.off_tri;
-            const uint32_t o_pmat = KERNEL == 3 ? sc.g_off_pmat : sc.off_pmat;
-            const uint32_t o_mats = KERNEL == 3 ? sc.g_off_mats : sc.off_mats;
-            if (pid < sc.n_sph + sc.n_mov) {
-              V3 center;
-              bool inward;  // negative radius: only the sign of the signed r*r is used here
-              if (pid < sc.n_sph) {
-                const double2 p0 = im.d2(o_sph + 32u * (uint32_t)pid), p1 = im.d2(o_sph + 32u * (uint32_t)pid + 16u);
-                center = {(real)p0.x, (real)p0.y, (real)p1.x};
-                inward = p1.y < 0.0;
-              } else {
-                const uint32_t r = o_mov + 64u * (uint32_t)(pid - sc.n_sph);
-                const double2 p0 = im.d2(r), p1 = im.d2(r + 16u), p2 = im.d2(r + 32u), p3 = im.d2(r + 48u);
-#ifdef RTOW_REAL_F32
-                center = {(real)p0.x + rtime * (real)p1.y, (real)p0.y + rtime * (real)p2.x, (real)p1.x + rtime * (real)p2.y};
-#else
-                center = {p0.x + rtime * p1.y, p0.y + rtime * p2.x, p1.x + rtime * p2.y};
-#endif
-                inward = p3.x < 0.0;
-              }
-              normal = normalize(where - center);
-              front = (dot(rd, normal) < real(0.0)) ^ inward;
-              normal = front ? normal : -normal;
-            } else {
-#ifdef RTOW_REAL_F32
-              const uint32_t r = o_tri + 48u * (uint32_t)(pid - sc.n_sph - sc.n_mov);
-              const float4 q2 = im.f4(r + 32u);
-              normal = {q2.y, q2.z, q2.w};
-#else
-              const uint32_t r = o_tri + 96u * (uint32_t)(pid - sc.n_sph - sc.n_mov);
-              const double2 q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
-              normal = {q4.y, q5.x, q5.y};
-#endif
-            }
-            mi = (int)im.u32(o_pmat + 4u * (uint32_t)pid);
-            const uint32_t mr = o_mats + 48u * (uint32_t)mi;
-            const double2 m1 = im.d2(mr + 16u), m2 = im.d2(mr + 32u);  // {att.z, fuzz}, {ir, kind|pad}
-#ifdef RTOW_FAST_MATH
-            const double2 m0 = im.d2(mr);  // {att.x, att.y}
-            m_att = V3{(real)m0.x, (real)m0.y, (real)m1.x};
-#endif
-            m_fuzz = (real)m1.y;
-            m_ir = (real)m2.x;
-            kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
-          } else {
-            if (pid < sc.n_sph + sc.n_mov) {
-              V3 center;
-              bool inward;
-              if (pid < sc.n_sph) {
-                const double *q = sc.sph + 4 * (size_t)pid;
-                center = {(real)q[0], (real)q[1], (real)q[2]};
-                inward = sc.sph_r[pid] < 0.0;
-              } else {
-                const double *q = sc.mov + 8 * (size_t)(pid - sc.n_sph);
-#ifdef RTOW_REAL_F32
-                center = {(real)q[0] + rtime * (real)q[3], (real)q[1] + rtime * (real)q[4], (real)q[2] + rtime * (real)q[5]};
-#else
-                center = {q[0] + rtime * q[3], q[1] + rtime * q[4], q[2] + rtime * q[5]};
-#endif
-                inward = q[7] < 0.0;
-              }
-              normal = normalize(where - center);
-              front = (dot(rd, normal) < real(0.0)) ^ inward;
-              normal = front ? normal : -normal;
-            } else {
-              const double *q = sc.tri + 12 * (size_t)(pid - sc.n_sph - sc.n_mov);
-              normal = {(real)q[9], (real)q[10], (real)q[11]};
-            }
-            mi = sc.prim_mat[pid];
-            const DevMaterial *m = sc.mats + mi;
-#ifdef RTOW_FAST_MATH
-            m_att = V3{(real)m->att[0], (real)m->att[1], (real)m->att[2]};
-#endif
-            kind = m->kind;
-            m_fuzz = (real)m->fuzz;
-            m_ir = (real)m->ir;
-          }
-
-          // ---- Material::scatter (src/common-model.cpp:13-62) ------------------
-          V3 dir;
-          const bool absorbed = !scatter_dir(g, k0, k1, kind, m_fuzz, m_ir, rd, normal, front, dir);
-          if (absorbed) {
-            need_sample = true;  // src/render.cpp:120: black
-          } else {
-#ifdef RTOW_FAST_MATH
-            throughput = throughput * m_att;
-#else
-            P.stack[(size_t)nb * P.n_lanes + lane_g] = (uint32_t)mi;
-#endif
-            ++nb;
-            --depth;
-            ro = where;
-            rd = dir;
-          }
-        }
+        else
+          pending_hit = true;  // scattered at the top of the next trip, together with the new camera rays
       } else {
         // ---- background + unwind of the recursion (src/render.cpp:119,122-128) --
         const V3 unit = normalize(rd);

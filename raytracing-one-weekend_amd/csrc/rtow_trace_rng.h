@@ -9,7 +9,10 @@ struct Rng {
 // Philox4x32-7: the fastest member of the family reported Crush-resistant (Salmon et al.,
 // SC'11); oracle/ uses the same round count (its tests pin the round function with the
 // published 10-round known answers).
-constexpr int kPhiloxRounds = 7;
+#ifndef RTOW_PHILOX_ROUNDS
+#define RTOW_PHILOX_ROUNDS 7
+#endif
+constexpr int kPhiloxRounds = RTOW_PHILOX_ROUNDS;  // (the macro exists for timing experiments only)
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                            uint32_t k0, uint32_t k1, uint32_t &o0, uint32_t &o1,
                                            uint32_t &o2, uint32_t &o3) {
@@ -37,17 +40,21 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 // One request = one block (w0..w3); see oracle/rtow_oracle.cpp, struct PhiloxDraw.
 // First block of a sample: pixel jitter + shutter time, 21 bits each (top bits of words 0..2), and
 // the first lens-disk candidate, 32 bits per coordinate (word 3; the 11+11+10 low bits of words 0..2).
-__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, real &u, real &v, real &t, real &da,
-                                           real &db) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
+__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, real &u, real &v,
+                                                  real &t, real &da, real &db) {
   const real s21 = real(0x1p-21), s32 = real(0x1p-32);
   u = (real)(o0 >> 11) * s21;
   v = (real)(o1 >> 11) * s21;
   t = (real)(o2 >> 11) * s21;
   da = (real)o3 * s32;
   db = (real)((o0 & 0x7ffu) | ((o1 & 0x7ffu) << 11) | ((o2 & 0x3ffu) << 22)) * s32;
+}
+__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, real &u, real &v, real &t, real &da,
+                                           real &db) {
+  uint32_t o0, o1, o2, o3;
+  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
+  jitter_from_block(o0, o1, o2, o3, u, v, t, da, db);
 }
 // a further lens-disk block: two candidates, (w0, w1) and (w2, w3), 32 bits per coordinate
 __device__ __forceinline__ void rng_disk2(Rng &g, uint32_t k0, uint32_t k1, real &a0, real &b0, real &a1, real &b1) {

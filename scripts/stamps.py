@@ -29,6 +29,7 @@ for i, n in enumerate(["large list", "walk set-up", "hit record", "rejection", "
 iters, trips, phases = out[13], out[14], out[15]
 print(f"wave trips {trips}, step-loop iterations per trip {iters/max(trips,1):.1f}, leaf phases per trip {phases/max(trips,1):.2f}, "
       f"lane-segments per trip {st.segments/max(trips,1):.1f} of 64")
+print(f"Philox block evaluations per trip (wave level, new-ray stage): {out[44]/max(trips,1):.2f}")
 nw = 4096.0
 print(f"wave end times (ms after first wave start): mean {out[4]/nw/1e5:.3f}  min {out[5]/1e5:.3f}  max {out[6]/1e5:.3f};  queue seen empty (mean over waves) {out[7]/nw/1e5:.3f}")
 
