@@ -32,6 +32,10 @@
 
 namespace rtow {
 
+#ifndef RTOW_BVH4_NODE_BYTES
+#define RTOW_BVH4_NODE_BYTES 128  // stride of a node record (a multiple of 32; see rtow_trace_bvh4.h)
+#endif
+constexpr uint32_t kBvh4NodeBytes = RTOW_BVH4_NODE_BYTES;
 constexpr uint32_t kRefNone = 0x1fffffu;
 constexpr uint32_t kRefLeaf = 1u << 20;
 constexpr uint32_t kBvh4MaxNodes = 1u << 20;
@@ -114,7 +118,7 @@ inline void make_bvh4_image(const HostBvh &bvh, const std::vector<double> &tri, 
   const size_t n4count = nodes.size();
 
   auto up16 = [](size_t v) { return (v + 15) / 16 * 16; };
-  const size_t nodes_bytes = n4count * 128;
+  const size_t nodes_bytes = n4count * kBvh4NodeBytes;
   img.off_tri = (uint32_t)nodes_bytes;
   img.off_pmat = (uint32_t)up16(img.off_tri + nt * 96);
   img.off_mats = (uint32_t)up16(img.off_pmat + nt * 4);
@@ -130,8 +134,8 @@ inline void make_bvh4_image(const HostBvh &bvh, const std::vector<double> &tri, 
   const float inf = INFINITY;
   for (size_t i = 0; i < n4count; ++i) {
     const N4 &n4 = nodes[i];
-    float *f = reinterpret_cast<float *>(B + i * 128);
-    uint32_t *cw = reinterpret_cast<uint32_t *>(B + i * 128 + 96);
+    float *f = reinterpret_cast<float *>(B + i * kBvh4NodeBytes);
+    uint32_t *cw = reinterpret_cast<uint32_t *>(B + i * kBvh4NodeBytes + 96);
     for (int c = 0; c < 4; ++c) {
       if (c >= n4.n) {  // empty slot
         for (int k = 0; k < 3; ++k) {
@@ -175,7 +179,7 @@ inline bool validate_bvh4_image(const Bvh4Image &img, size_t n_tri) {
   level[0] = 1;
   int depth = 1;
   for (int i = 0; i < img.n_nodes; ++i) {
-    const uint32_t *cw = reinterpret_cast<const uint32_t *>(img.blob.data() + (size_t)i * 128 + 96);
+    const uint32_t *cw = reinterpret_cast<const uint32_t *>(img.blob.data() + (size_t)i * kBvh4NodeBytes + 96);
     if (level[i] == 0) return false;  // unreachable node
     for (int c = 0; c < 4; ++c) {
       const uint32_t r = cw[c];

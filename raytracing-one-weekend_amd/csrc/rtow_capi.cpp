@@ -855,7 +855,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
       K = std::min<uint32_t>((kLdsLimit - staged) / per_entry, 32u);
     } else {
       K = c->knobs.bvh4_stack_k > 0 ? std::min<uint32_t>((uint32_t)c->knobs.bvh4_stack_k, 32u) : 24u;
-      staged = std::min<uint32_t>((kLdsLimit - K * per_entry) / 128u * 128u, scene.b4_off_tri);
+      staged = std::min<uint32_t>((kLdsLimit - K * per_entry) / rtow::kBvh4NodeBytes * rtow::kBvh4NodeBytes, scene.b4_off_tri);
     }
     K = std::min<uint32_t>(K, (uint32_t)stack_bound);
     scene.b4_lds_limit = staged;
@@ -960,6 +960,10 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
       cap = b4 ? 4 : 3;
       open = b4 ? (b4_full ? 24 : 40) : 16;
     }
+    // GRID: a resumed lane re-enters one cell BEHIND the cell it stopped at (rtow_trace_grid.h), and up to
+    // two cell crossings can share one ray parameter (a ray through a cell corner), so fewer than 3 steps
+    // per trip would not guarantee progress (cap 1 is a livelock).  BVH4 resumes exactly where it stopped.
+    if (cap > 0 && !b4) cap = std::max(cap, 3);
     P.walk_cap = cap > 0 ? (uint32_t)cap : 0xffffffffu;
     P.walk_max_open = (uint32_t)open;
     P.leaf_votes = (uint32_t)(c->knobs.leaf_votes > 0 ? c->knobs.leaf_votes : (b4 ? 24 : 16));

@@ -19,6 +19,10 @@
 //     is staged whole, a big one has the top of its tree (breadth-first node order) in LDS.
 // Termination: child links only point to later nodes (validated at upload), so every node is entered
 // at most once per ray; every loop trip either pops, enters a node, queues a leaf or runs the leaf phase.
+#ifndef RTOW_BVH4_NODE_BYTES
+#define RTOW_BVH4_NODE_BYTES 128
+#endif
+constexpr uint32_t kBvh4NodeBytes = RTOW_BVH4_NODE_BYTES;  // rtow_bvh4.h
 constexpr uint32_t kRefNone = 0x1fffffu;   // rtow_bvh4.h
 constexpr uint32_t kRefLeaf = 1u << 20;
 constexpr uint32_t kRefPop = 0x1ffffeu;    // traversal state only: take the next entry from the stack
@@ -123,7 +127,7 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
     }
     // (3) one node: four slab tests, nearest hit child next, the others to the stack
     if (cur < kRefLeaf) {
-      const uint32_t nb = cur << 7;
+      const uint32_t nb = cur * kBvh4NodeBytes;
       vf4 nx, fx, ny, fy, nz, fz;
       vu4 cw;
       if (FULL || nb < im.lds_limit) {

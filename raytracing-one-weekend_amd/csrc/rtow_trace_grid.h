@@ -16,7 +16,9 @@
 // (`best`) and the ray parameter at which it entered its current cell (`t_resume` > 0).  The caller
 // shades the finished lanes as usual and calls again in its next trip; a resumed lane skips the
 // large-primitive list and re-enters the grid at t_resume (a hair earlier: the cell containing that
-// point or its predecessor, so no cell is skipped; a cell tested twice changes nothing).
+// point or its predecessor, so no cell is skipped; a cell tested twice changes nothing).  Because of that
+// step back, `cap` must be at least 3 (the host clamps it): at most two consecutive cell crossings share one
+// ray parameter, so three steps always end in a cell that starts later than the one the lane resumed in.
 template <bool LDS, bool ST>
 __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const DevScene &sc, V3 o,
                                                     V3 d, real time, bool active, uint32_t &nnode,

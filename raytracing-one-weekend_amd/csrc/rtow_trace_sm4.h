@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
       }
       // (3) one node: four slab tests, nearest hit child next, the others to the stack
       if (walking && cur < kRefLeaf) {
-        const uint32_t nbase = cur << 7;
+        const uint32_t nbase = cur * kBvh4NodeBytes;
         vf4 nx, fx, ny, fy, nz, fz;
         vu4 cw;
         if (FULL || nbase < im.lds_limit) {

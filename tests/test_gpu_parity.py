@@ -508,6 +508,33 @@ def test_rtweekend_gpus_flag_partitions_like_one_device(ctx):
     assert bad.returncode != 0
 
 
+@pytest.mark.parametrize("env", [
+    {"RTOW_WALK_CAP": "off", "RTOW_LEAF_VOTES": "1", "RTOW_FETCH_VOTES": "1"},   # every scheduling measure off
+    {"RTOW_WALK_CAP": "1,64", "RTOW_LEAF_VOTES": "64", "RTOW_FETCH_VOTES": "64"},  # ... at its extreme (the grid's cap is clamped to 3)
+    {"RTOW_BVH4_SM": "1"},                                                           # state-machine BVH4 kernel
+    {"RTOW_BVH4_SM": "1", "RTOW_SM4_VOTES": "64,64,64"},
+    {"RTOW_BVH4_STACK_K": "2"},                                                      # nearly everything spills
+    {"RTOW_NO_BVH4": "1"},                                                           # meshes on the binary walk
+], ids=["plain", "extreme", "sm4", "sm4-64", "spill", "bvh2"])
+def test_scheduling_knobs_do_not_change_the_image(monkeypatch, env):
+    """Resumable walks, leaf / fetch quorums, the state-machine form of the BVH4 kernel and the size of the
+    LDS stack only decide WHEN a lane does its work: with any setting the strict image is the oracle's, bit
+    for bit, on the sphere scene (GRID) and on the mesh (BVH4).  (Knobs are read when a context is created.)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = rtow.Context(0)
+    try:
+        for scene, cfg in (
+            (rtow.HostScene.cover(11, 1.5, True), rtow.make_config(240, 160, 8, 2, 50, seed=3, precision=rtow.F64_STRICT)),
+            (rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9), rtow.make_config(320, 180, 8, 2, 20, seed=4, precision=rtow.F64_STRICT)),
+        ):
+            img, st = c.render(scene, cfg)
+            ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=16, accel=True)
+            assert st.segments == ost.segments and np.array_equal(img, ref), (env, int((img != ref).sum()))
+    finally:
+        c.close()
+
+
 def test_rtweekend_rccl_path_with_one_rank(ctx):
     """rtow_render_multi (the single-process multi-device form): with use_rccl the strips go through a
     real RCCL communicator (ncclCommInitAll, one ncclGather, one D2H).  A one-GPU box can only hold a
