@@ -26,6 +26,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
                                                     float &t_resume, uint32_t cap, uint32_t max_open,
                                                     uint32_t leaf_votes) {
   const bool resumed = t_resume > 0.0f;
+  const float t_in = t_resume;
   if (!resumed) {
     best.t = (real)__builtin_huge_val();
     best.prim = -1;
@@ -150,7 +151,11 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
     const bool any_walking = m_walking != 0ull;
     ++trips;
     // stop here and resume in the caller's next trip?  (never on the first trips: most lanes finish there)
-    const bool suspend = any_walking && trips >= cap && (uint32_t)__popcll(m_walking) <= max_open;
+    // ... never before every resumed lane has got strictly beyond the point it resumed at: progress of a
+    // resumed walk is then structural (t_entry takes finitely many f32 values), whatever the rounding does
+    // when a ray runs through a cell corner
+    const bool suspend = any_walking && trips >= cap && (uint32_t)__popcll(m_walking) <= max_open &&
+                         __ballot(walking && resumed && !(t_entry > t_in)) == 0ull;
     // leaf phase: when `leaf_votes` lanes hold a queued cell, when no lane can take a step, or at the end
     const unsigned long long m_pending = __ballot(q0 != 0u);
     if ((m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= leaf_votes || __ballot(walking && q1 == 0u) == 0ull)) ||
