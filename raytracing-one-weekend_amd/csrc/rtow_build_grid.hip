@@ -174,19 +174,29 @@ __global__ void kg_finish_cells(const uint32_t *count, const uint32_t *first, in
   reinterpret_cast<uint32_t *>(blob + off_cells)[c] = cnt ? (f << 8) | cnt : 0u;
 }
 
-// fat cell lists (rtow_grid.h): id + sphere record side by side, same order as the id list
-__global__ void kg_fat_lists(const double *sph, unsigned long long total_ids, unsigned char *blob, uint32_t off_ids,
-                             uint32_t off_fat) {
+// fat cell lists (rtow_grid.h): id + sphere record side by side, same order as the id list; 48-byte entries
+// for static scenes, 80-byte entries [id . . .][c0x c0y][c0z dx][dy dz][r2 .] when some spheres move
+__global__ void kg_fat_lists(const double *sph, const double *mov, int ns, unsigned long long total_ids,
+                             unsigned char *blob, uint32_t off_ids, uint32_t off_fat, uint32_t stride) {
   const unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total_ids) return;
   const uint32_t id = reinterpret_cast<const uint32_t *>(blob + off_ids)[e];
-  unsigned char *dst = blob + off_fat + e * 48ull;
+  unsigned char *dst = blob + off_fat + e * (unsigned long long)stride;
   reinterpret_cast<uint32_t *>(dst)[0] = id;
   reinterpret_cast<uint32_t *>(dst)[1] = 0u;
   reinterpret_cast<uint32_t *>(dst)[2] = 0u;
   reinterpret_cast<uint32_t *>(dst)[3] = 0u;
   double *rec = reinterpret_cast<double *>(dst + 16);
-  for (int k = 0; k < 4; ++k) rec[k] = sph[(size_t)id * 4 + k];
+  if (stride == 48u) {
+    for (int k = 0; k < 4; ++k) rec[k] = sph[(size_t)id * 4 + k];
+  } else if ((int)id < ns) {
+    const double *q = sph + (size_t)id * 4;
+    rec[0] = q[0], rec[1] = q[1], rec[2] = q[2], rec[3] = 0.0, rec[4] = 0.0, rec[5] = 0.0, rec[6] = q[3], rec[7] = 0.0;
+  } else {
+    const double *q = mov + ((size_t)id - (size_t)ns) * 8;
+    for (int k = 0; k < 7; ++k) rec[k] = q[k];
+    rec[7] = 0.0;
+  }
 }
 
 __global__ void kg_large_list(const uint32_t *is_large, const uint32_t *large_rank, int n, unsigned char *blob,
@@ -336,7 +346,7 @@ int grid_build_phase2(void *handle, const float gminf[3], const float cellf[3], 
 // fill + sort the cell lists, write cell words, ids and the large list into the image
 int grid_build_phase3(void *handle, const float gminf[3], const float cellf[3], const int32_t n[3], double pad,
                       unsigned long long total_ids, unsigned char *blob_dev, uint32_t off_cells, uint32_t off_ids,
-                      void *stream, const double *sph, uint32_t off_fat) {
+                      void *stream, const double *sph, uint32_t off_fat, const double *mov, int ns, uint32_t fat_stride) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   GScratch *s = static_cast<GScratch *>(handle);
   if (!s) return 1;
@@ -360,8 +370,8 @@ int grid_build_phase3(void *handle, const float gminf[3], const float cellf[3], 
   hipLaunchKernelGGL(kg_finish_cells, dim3((ncell + B - 1) / B), dim3(B), 0, st, s->count, s->first, ncell,
                      s->ids_tmp, blob_dev, off_cells, off_ids);
   if (off_fat != 0u && total_ids > 0)
-    hipLaunchKernelGGL(kg_fat_lists, dim3((unsigned)((total_ids + B - 1) / B)), dim3(B), 0, st, sph, total_ids, blob_dev,
-                       off_ids, off_fat);
+    hipLaunchKernelGGL(kg_fat_lists, dim3((unsigned)((total_ids + B - 1) / B)), dim3(B), 0, st, sph, mov, ns, total_ids,
+                       blob_dev, off_ids, off_fat, fat_stride);
   hipLaunchKernelGGL(kg_large_list, dim3((s->n + B - 1) / B), dim3(B), 0, st, s->is_large, s->large_rank, s->n,
                      blob_dev, off_ids + 4u * (uint32_t)total_ids);
   const bool good = hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;

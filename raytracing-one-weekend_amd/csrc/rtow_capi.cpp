@@ -186,7 +186,7 @@ int grid_build_phase2(void *handle, const float gminf[3], const float cellf[3], 
                       void *stream, unsigned long long *total_ids, unsigned long long *max_list);
 int grid_build_phase3(void *handle, const float gminf[3], const float cellf[3], const int32_t n[3], double pad,
                       unsigned long long total_ids, unsigned char *blob_dev, uint32_t off_cells, uint32_t off_ids,
-                      void *stream, const double *sph, uint32_t off_fat);
+                      void *stream, const double *sph, uint32_t off_fat, const double *mov, int ns, uint32_t fat_stride);
 void grid_build_release(void *handle);
 }  // namespace rtow
 
@@ -560,15 +560,15 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
       if (max_list <= 255 && total_ids + (unsigned long long)gb.n_large < (1u << 24)) {
         const size_t ncell = (size_t)hd.n[0] * hd.n[1] * hd.n[2];
         for (int k = 0; k < 3; ++k) gimg.n[k] = hd.n[k];
-        const bool fat = rtow::grid_wants_fat_lists(nm, nt, ncell, (size_t)total_ids + (size_t)gb.n_large,
-                                                    (size_t)gb.n_large, sph, mov, tri, pmat, mats_bytes, (size_t)total_ids);
+        const uint32_t fat = rtow::grid_wants_fat_lists(nm, nt, ncell, (size_t)total_ids + (size_t)gb.n_large,
+                                                        (size_t)gb.n_large, sph, mov, tri, pmat, mats_bytes, (size_t)total_ids);
         rtow::layout_grid_image(ncell, (size_t)total_ids + (size_t)gb.n_large, (size_t)gb.n_large, sph, mov, tri, pmat,
-                                mats_bytes, gimg, true, fat ? (size_t)total_ids : 0);
+                                mats_bytes, gimg, true, fat ? (size_t)total_ids : 0, fat ? fat : 48u);
         if ((rc = c->gblob.ensure(gimg.total_bytes))) return rc;
         unsigned char *gp = (unsigned char *)c->gblob.p;
         unsigned char header[64];
         const uint32_t off_large = (uint32_t)(gimg.off_ids + total_ids * 4);
-        rtow::write_grid_header(header, hd, gimg.n_large, off_large, gimg.off_fat);
+        rtow::write_grid_header(header, hd, gimg.n_large, off_large, gimg.off_fat, gimg.fat_stride);
         HIPCHK(hipMemsetAsync(gp, 0, gimg.total_bytes, nullptr));
         HIPCHK(hipMemcpyAsync(gp, header, 64, hipMemcpyHostToDevice, nullptr));
         if (ns) HIPCHK(hipMemcpyAsync(gp + gimg.off_sph, c->sph.p, sph.size() * 8, hipMemcpyDeviceToDevice, nullptr));
@@ -577,7 +577,8 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
         HIPCHK(hipMemcpyAsync(gp + gimg.off_pmat, c->prim_mat.p, pmat.size() * 4, hipMemcpyDeviceToDevice, nullptr));
         HIPCHK(hipMemcpyAsync(gp + gimg.off_mats, c->mats.p, mats_bytes.size(), hipMemcpyDeviceToDevice, nullptr));
         grc = rtow::grid_build_phase3(c->grid_scratch, hd.gminf, hd.cellf, hd.n, hd.pad, total_ids, gp, gimg.off_cells,
-                                      gimg.off_ids, nullptr, (const double *)c->sph.p, gimg.off_fat);
+                                      gimg.off_ids, nullptr, (const double *)c->sph.p, gimg.off_fat,
+                                      (const double *)c->mov.p, ns, gimg.fat_stride);
         if (grc) return fail(RTOW_EHIP, "device grid build failed (phase 3, stage %d): %s", grc, hipGetErrorString(hipGetLastError()));
         gimg.ok = true;
       }

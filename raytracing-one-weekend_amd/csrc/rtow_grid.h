@@ -33,6 +33,7 @@ struct GridImage {
   uint32_t n_large = 0;
   size_t total_bytes = 0;
   uint32_t off_fat = 0;
+  uint32_t fat_stride = 0;  // bytes per fat list entry: 48 (static spheres) or 80 (scenes with moving spheres)
   bool ok = false;  // false: scene not suited (e.g. lists too long) — use the BVH
 };
 
@@ -91,16 +92,20 @@ inline void grid_header(const double gmn_in[3], const double gmx_in[3], double s
 inline void layout_grid_image(size_t ncell, size_t total_ids, size_t n_large, const std::vector<double> &sph,
                               const std::vector<double> &mov, const std::vector<double> &tri,
                               const std::vector<int32_t> &prim_mat, const std::vector<unsigned char> &mats_bytes,
-                              GridImage &img, bool offsets_only = false, size_t fat_entries = 0) {
+                              GridImage &img, bool offsets_only = false, size_t fat_entries = 0,
+                              uint32_t fat_stride = 48) {
   const size_t hdr = 64;
   img.off_cells = (uint32_t)hdr;
   const size_t cells_bytes = ((ncell * 4 + 15) / 16) * 16;
   img.off_ids = (uint32_t)(hdr + cells_bytes);
   const size_t ids_bytes = ((total_ids * 4 + 15) / 16) * 16;
-  // "fat" cell lists: id + sphere record side by side (48 B per entry, same order as the id list), so a
-  // cell test is ONE round of LDS reads instead of id -> record (static spheres only)
+  // "fat" cell lists: id + sphere record side by side (same order as the id list), so a cell test is ONE
+  // round of LDS reads instead of id -> record.  48 B per entry [id . . .][cx cy][cz r2] when all small
+  // spheres are static; 80 B [id . . .][c0x c0y][c0z dx][dy dz][r2 .] when some move (a static sphere
+  // then has d = 0)
   img.off_fat = fat_entries ? (uint32_t)(img.off_ids + ids_bytes) : 0u;
-  img.off_sph = (uint32_t)(img.off_ids + ids_bytes + fat_entries * 48);
+  img.fat_stride = fat_entries ? fat_stride : 0u;
+  img.off_sph = (uint32_t)(img.off_ids + ids_bytes + fat_entries * fat_stride);
   img.off_mov = img.off_sph + (uint32_t)(sph.size() * 8);
   img.off_tri = img.off_mov + (uint32_t)(mov.size() * 8);
   img.off_pmat = (uint32_t)((((size_t)img.off_tri + tri.size() * 8) + 15) / 16 * 16);
@@ -116,9 +121,10 @@ inline void layout_grid_image(size_t ncell, size_t total_ids, size_t n_large, co
 
 // the 64-byte image header (see the layout comment at the top)
 inline void write_grid_header(unsigned char *h, const GridHeader &hd, uint32_t n_large, uint32_t off_large,
-                              uint32_t off_fat = 0) {
+                              uint32_t off_fat = 0, uint32_t fat_stride = 0) {
   std::memset(h, 0, 64);
   std::memcpy(h + 56, &off_fat, 4);
+  std::memcpy(h + 60, &fat_stride, 4);
   std::memcpy(h + 0, hd.gminf, 12);
   std::memcpy(h + 12, hd.cellf, 12);
   std::memcpy(h + 24, hd.invf, 12);
@@ -127,16 +133,38 @@ inline void write_grid_header(unsigned char *h, const GridHeader &hd, uint32_t n
   std::memcpy(h + 52, &off_large, 4);
 }
 
-// Fat cell lists (id + sphere record per list entry): for scenes made of static spheres only, and only
-// if the image still fits the 160 KiB of LDS with them (shared by the host and the device builder).
-inline bool grid_wants_fat_lists(int n_moving, int n_triangles, size_t ncell, size_t total_ids, size_t n_large,
-                                 const std::vector<double> &sph, const std::vector<double> &mov,
-                                 const std::vector<double> &tri, const std::vector<int32_t> &prim_mat,
-                                 const std::vector<unsigned char> &mats_bytes, size_t n_cell_ids) {
-  if (n_moving != 0 || n_triangles != 0 || n_cell_ids == 0 || std::getenv("RTOW_GRID_NO_FAT")) return false;
+// Fat cell lists (id + sphere record per list entry): for scenes made of spheres only, and only if the
+// image still fits the 160 KiB of LDS with them (shared by the host and the device builder).  Returns the
+// entry size: 0 = no fat lists, 48 = static spheres only, 80 = some spheres move.
+inline uint32_t grid_wants_fat_lists(int n_moving, int n_triangles, size_t ncell, size_t total_ids, size_t n_large,
+                                     const std::vector<double> &sph, const std::vector<double> &mov,
+                                     const std::vector<double> &tri, const std::vector<int32_t> &prim_mat,
+                                     const std::vector<unsigned char> &mats_bytes, size_t n_cell_ids) {
+  if (n_triangles != 0 || n_cell_ids == 0 || std::getenv("RTOW_GRID_NO_FAT")) return 0u;
+  const uint32_t stride = n_moving != 0 ? 80u : 48u;
+  if (stride == 80u && std::getenv("RTOW_GRID_NO_FAT_MOVING")) return 0u;
   GridImage probe;
-  layout_grid_image(ncell, total_ids, n_large, sph, mov, tri, prim_mat, mats_bytes, probe, true, n_cell_ids);
-  return probe.total_bytes <= 160u * 1024u;
+  layout_grid_image(ncell, total_ids, n_large, sph, mov, tri, prim_mat, mats_bytes, probe, true, n_cell_ids, stride);
+  return probe.total_bytes <= 160u * 1024u ? stride : 0u;
+}
+
+// one fat entry (host builder; rtow_build_grid.hip has the device twin)
+inline void write_fat_entry(unsigned char *dst, uint32_t stride, int32_t id, const std::vector<double> &sph,
+                            const std::vector<double> &mov) {
+  const size_t ns = sph.size() / 4;
+  std::memset(dst, 0, stride);
+  std::memcpy(dst, &id, 4);
+  if (stride == 48u) {
+    std::memcpy(dst + 16, &sph[(size_t)id * 4], 32);
+  } else if ((size_t)id < ns) {
+    const double *q = &sph[(size_t)id * 4];
+    const double rec[8] = {q[0], q[1], q[2], 0.0, 0.0, 0.0, q[3], 0.0};
+    std::memcpy(dst + 16, rec, 64);
+  } else {
+    const double *q = &mov[((size_t)id - ns) * 8];  // c0xyz dxyz r2 r
+    const double rec[8] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], 0.0};
+    std::memcpy(dst + 16, rec, 64);
+  }
 }
 
 // sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
@@ -240,12 +268,12 @@ inline void build_grid_image(const std::vector<double> &sph, const std::vector<d
   }
   if (total_ids >= (1u << 24)) return;
 
-  // fat lists: scenes of static spheres only, when the image still fits LDS with them
+  // fat lists: scenes of spheres only, when the image still fits LDS with them
   const size_t n_cell_ids = total_ids - large.size();
-  const bool fat = grid_wants_fat_lists(nm, nt, (size_t)ncell, total_ids, large.size(), sph, mov, tri, prim_mat,
-                                        mats_bytes, n_cell_ids);
+  const uint32_t fat = grid_wants_fat_lists(nm, nt, (size_t)ncell, total_ids, large.size(), sph, mov, tri, prim_mat,
+                                            mats_bytes, n_cell_ids);
   layout_grid_image((size_t)ncell, total_ids, large.size(), sph, mov, tri, prim_mat, mats_bytes, img, false,
-                    fat ? n_cell_ids : 0);
+                    fat ? n_cell_ids : 0, fat ? fat : 48u);
 
   std::vector<int32_t> ids;
   ids.reserve(total_ids);
@@ -259,15 +287,10 @@ inline void build_grid_image(const std::vector<double> &sph, const std::vector<d
   ids.insert(ids.end(), large.begin(), large.end());
 
   unsigned char *h = img.blob.data();
-  write_grid_header(h, hd, img.n_large, off_large, img.off_fat);
-  if (img.off_fat) {
-    for (size_t e = 0; e < n_cell_ids; ++e) {
-      unsigned char *dst = h + img.off_fat + e * 48;
-      const int32_t id = ids[e];
-      std::memcpy(dst, &id, 4);
-      std::memcpy(dst + 16, &sph[(size_t)id * 4], 32);
-    }
-  }
+  write_grid_header(h, hd, img.n_large, off_large, img.off_fat, img.fat_stride);
+  if (img.off_fat)
+    for (size_t e = 0; e < n_cell_ids; ++e)
+      write_fat_entry(h + img.off_fat + e * img.fat_stride, img.fat_stride, ids[e], sph, mov);
   std::memcpy(h + img.off_cells, cells.data(), cells.size() * 4);
   if (!ids.empty()) std::memcpy(h + img.off_ids, ids.data(), ids.size() * 4);
   if (!sph.empty()) std::memcpy(h + img.off_sph, sph.data(), sph.size() * 8);

@@ -40,6 +40,7 @@ __device__ __forceinline__ float safe_inv(float d) {
 struct ImgOffsets {  // byte offsets of the id and record sections inside a scene image
   uint32_t ids, sph, mov, tri;
   uint32_t fat;           // grid image: id + sphere record side by side per list entry (0 = none)
+  uint32_t fat_stride;    // ... bytes per entry: 48 (static spheres) or 80 (c0, delta, r2: scenes with moving spheres)
   uint32_t sph32, mov32;  // f32 build: binary32 copies of the sphere records (grid cells); `tri` then
                           // points at binary32 triangle records (48 B), the only triangle section
 };
@@ -83,14 +84,30 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
 #ifndef RTOW_REAL_F32
   if constexpr (SMALL) {
     if (off.fat != 0u) {  // wave-uniform: one round of LDS reads per entry instead of id -> record
-      for (uint32_t k = 0; k < count; ++k) {
-        const uint32_t e = off.fat + 48u * (first + k);
-        const int id = (int)im.u32(e);
-        const double2 p0 = im.d2(e + 16u), p1 = im.d2(e + 32u);
-        if (id == last_id) continue;
-        last_id = id;
-        ++nprim;
-        sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+      if (off.fat_stride == 48u) {
+        for (uint32_t k = 0; k < count; ++k) {
+          const uint32_t e = off.fat + 48u * (first + k);
+          const int id = (int)im.u32(e);
+          const double2 p0 = im.d2(e + 16u), p1 = im.d2(e + 32u);
+          if (id == last_id) continue;
+          last_id = id;
+          ++nprim;
+          sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+        }
+      } else {  // entries with motion: centre(time) = c0 + time * delta (src/oo-primitives.h:64-66; delta = 0 if static)
+        for (uint32_t k = 0; k < count; ++k) {
+          const uint32_t e = off.fat + 80u * (first + k);
+          const int id = (int)im.u32(e);
+          const double2 p0 = im.d2(e + 16u), p1 = im.d2(e + 32u), p2 = im.d2(e + 48u), p3 = im.d2(e + 64u);
+          if (id == last_id) continue;
+          last_id = id;
+          ++nprim;
+          // (a static sphere's delta is +0: c0 + time * 0 is c0 exactly, time being finite)
+          const double cx = p0.x + ray.time64 * p1.y;
+          const double cy = p0.y + ray.time64 * p2.x;
+          const double cz = p1.x + ray.time64 * p2.y;
+          sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
+        }
       }
       return;
     }
@@ -161,7 +178,7 @@ __device__ __forceinline__ Closest closest_hit_bvh(const Image<LDS> &im, const D
   const float slack = 1.00002f;   // relative slack on the far side of the interval
   float tmax32 = __builtin_huge_valf();
   const uint32_t END = (uint32_t)sc.n_nodes;  // skip links past the last node point here
-  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri, 0u, sc.off_sph32, sc.off_mov32};
+  const ImgOffsets off = {sc.off_ids, sc.off_sph, sc.off_mov, sc.off_tri, 0u, 0u, sc.off_sph32, sc.off_mov32};
   int last_id = -1;
   uint32_t node = active ? 0u : END;  // the walk uses wave votes: idle lanes enter with nothing to do
   uint32_t q0 = 0u, q1 = 0u, q2 = 0u, q3 = 0u;  // queued leaves (0 = empty), oldest first

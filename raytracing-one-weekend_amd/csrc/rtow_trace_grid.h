@@ -32,7 +32,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
     best.prim = -1;
   }
   const RayForms ray = make_ray_forms(o, d, time);
-  ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri, 0u, sc.g_off_sph32, sc.g_off_mov32};
+  ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri, 0u, 0u, sc.g_off_sph32, sc.g_off_mov32};
   int last_id = -1;
   // header: wave-uniform scalar loads from the global copy of the image
   const RTOW_CONST float *hf = (const RTOW_CONST float *)sc.gblob;
@@ -43,6 +43,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   const int nx = hi[9], ny = hi[10], nz = hi[11];
   const uint32_t n_large = (uint32_t)hi[12], off_large = (uint32_t)hi[13];
   off.fat = (uint32_t)hi[14];
+  off.fat_stride = (uint32_t)hi[15];
 
   // the large primitives, for every ray.  Static spheres are taken four (then two) at a time:
   // all records are loaded and all discriminants computed before any hit branch, so LDS
