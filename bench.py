@@ -319,12 +319,19 @@ def timed_render_loop(ctx, cfg, d_ptr, stream, dev, steps, warmup):
     return el * 1e3, kms.value / max(nl.value, 1), st0
 
 
-def other_config(name, a, dev, precision, steps):
-    """One shortened line for another BASELINE config on this GPU (own context and scene)."""
+def other_config(name, a, dev, precision, steps, stress=False):
+    """One shortened line for another BASELINE config on this GPU (own context and scene).
+    `stress`: configs[4]'s "SoA primitive streaming" reading — the STREAM kernel, every wave streaming ALL
+    triangle records through scalar loads (960x540, 1 spp): the one line whose `roofline.achieved` is bytes
+    the kernel really moves (L2 / Infinity Cache to the scalar unit), not the equivalent-streaming figure."""
     kind, W, aspect, spp, depth, spi, base = WORKLOADS[name]
     scene, label = make_scene(kind)
+    if stress:
+        W, spp, spi = 960, 1, 1
+        base += " as a primitive-streaming stress (every ray tests every triangle)"
     H = rtow.image_height(W, aspect)
-    cfg = rtow.make_config(W, H, spp, max(1, spp // spi), depth, seed=SEED, precision=precision)
+    cfg = rtow.make_config(W, H, spp, max(1, spp // spi), depth, seed=SEED, precision=precision,
+                           kernel=rtow.KERNEL_BRUTE if stress else rtow.KERNEL_AUTO)
     ctx = rtow.Context(dev.index)
     ctx.upload(scene)
     bi = ctx.build_info()
@@ -544,6 +551,7 @@ def main():
         if world == 1 and a.workload == "cover" and not a.spp and not a.no_other_configs:
             out["other_configs"] = [other_config(n, a, dev, precision, s)
                                     for n, s in (("moving", 4), ("suzanne", 3), ("mesh100k", 2))]
+            out["other_configs"].append(other_config("mesh100k", a, dev, precision, 1, stress=True))
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, label, W, H, DEPTH, a.cpu_seconds)
         else:
