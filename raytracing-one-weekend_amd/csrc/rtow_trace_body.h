@@ -12,10 +12,12 @@
 //     from a global counter; the fetch is wave-aggregated (one atomic per wave per
 //     fetch round: __ballot + popcount ranks), so lanes stay dense until the
 //     queue is empty, and the image does not depend on which lane traced what.
-//   * ray regeneration.  Each trip of the main loop advances every live lane by
-//     exactly one ray segment; a lane whose path ended starts its next sample in
-//     the same trip, so the closest-hit step always runs on a full wave.
-//   * closest hit, two strategies with identical results:
+//   * one trip of the main loop = item bookkeeping, the NEW-RAY stage (camera rays of new samples and the
+//     scattered rays of last trip's hits, made together so that both share the Philox block evaluations), the
+//     closest-hit walk, and the end of the paths that escaped (sky colour) or ran out of bounces (black).
+//     Every lane with a ray advances by one segment per trip, so the walk runs on a full wave — unless its walk
+//     was stopped (most lanes done, a few not: GRID and BVH4 walks are resumable) and continues next trip.
+//   * closest hit, four strategies with identical results:
 //       STREAM — every lane tests every primitive.  The primitive index is
 //         wave-uniform, so each record is fetched with ONE scalar load into SGPRs and
 //         used directly as a VALU operand: the scene costs no VGPRs, no LDS traffic.
@@ -26,6 +28,9 @@
 //         the same f64 code as STREAM, so the accepted (t, primitive) is the same.
 //         Leaves found during the walk are queued per lane and tested in a separate
 //         phase, so the box loop and the primitive loop are each SIMT-dense.
+//       GRID — 3D-DDA over a uniform grid of the small primitives + an always-test list of the large
+//         ones (rtow_trace_grid.h); BVH4 — 4-wide BVH with a per-lane LDS stack for triangle meshes
+//         (rtow_trace_bvh4.h; rtow_trace_sm4.h is its state-machine form).
 //   * radiance.  The reference multiplies attenuations on the way back up the
 //     recursion, a1*(a2*(...*(an*sky))).  The STRICT build reproduces that order bit for bit:
 //     the lane records the material index of every bounce in a per-lane path stack in HBM
