@@ -423,6 +423,37 @@ def test_depth_zero_and_rounded_down_spp(ctx):
     assert st.samples == 0 and not img.any()
 
 
+@pytest.mark.parametrize("sm", [False, True])
+def test_bvh4_edge_cases(monkeypatch, sm):
+    """The 4-wide BVH kernel (trip form and state-machine form) on degenerate launches: images of one or two
+    pixels, a width that is not a multiple of the tile, zero bounces (every hit is black, src/render.cpp:113-115),
+    more streams than samples (zero effective samples), one sample per stream, a strip partition with empty
+    ranks — strict build against the oracle, bit for bit."""
+    if sm:
+        monkeypatch.setenv("RTOW_BVH4_SM", "1")
+    c = rtow.Context(0)
+    try:
+        scene = rtow.HostScene.obj(GOLDEN / "suzanne.obj", 1.5)
+        for (w, h, spp, ns, depth), part in (((2, 2, 3, 1, 20), (0, 1, 8)), ((65, 3, 4, 2, 20), (0, 1, 8)), ((1, 5, 2, 2, 20), (0, 1, 8)),
+                                             ((40, 24, 4, 4, 0), (0, 1, 8)), ((40, 24, 5, 5, 3), (0, 1, 8)),
+                                             ((33, 17, 4, 2, 20), (2, 3, 5)), ((16, 8, 4, 2, 20), (7, 8, 1)),
+                                             ((16, 8, 4, 2, 20), (5, 6, 4))):
+            rank, nranks, tile = part
+            cfg = rtow.make_config(w, h, spp, ns, depth, seed=w + h, precision=rtow.F64_STRICT, rank=rank, nranks=nranks,
+                                   tile_rows=tile)
+            img, st = c.render(scene, cfg)
+            ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=4, accel=True)
+            assert img.shape == ref.shape
+            if img.size:
+                assert st.kernel_used == rtow.KERNEL_BVH4
+                assert st.segments == ost.segments and np.array_equal(img, ref, equal_nan=True), (w, h, spp, ns, depth, part)
+        cfg = rtow.make_config(16, 8, 2, 3, 5, seed=1, precision=rtow.F64_STRICT)  # fewer samples than streams
+        img, st = c.render(scene, cfg)
+        assert st.samples == 0 and not img.any()
+    finally:
+        c.close()
+
+
 def test_error_paths(ctx):
     L = rtow.lib()
     fresh = rtow.Context(0)
