@@ -454,6 +454,27 @@ def test_bvh4_edge_cases(monkeypatch, sm):
         c.close()
 
 
+def test_mesh_beyond_the_bvh4_limits_takes_the_binary_walk(ctx, tmp_path):
+    """The 4-wide image addresses triangles with 18 bits (rtow_bvh4.h): a mesh of 279,752 triangles (suzanne
+    subdivided 17x17) is rendered by the binary threaded walk instead — same surface, so the image agrees with the
+    968-triangle original within Monte-Carlo noise; an explicit BVH4 request falls back, it does not fail."""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    obj = tmp_path / "mesh17.obj"
+    subprocess.run([sys.executable, str(REPO / "scripts" / "make_mesh.py"), str(obj), "17"], check=True, capture_output=True)
+    big = rtow.HostScene.obj(obj, 16 / 9)
+    assert big.c.n_triangles == 968 * 17 * 17
+    cfg = rtow.make_config(96, 54, 16, 2, 20, seed=13, precision=rtow.F64_FAST, kernel=rtow.KERNEL_BVH4)
+    a, st = ctx.render(big, cfg)
+    assert st.kernel_used == rtow.KERNEL_BVH and np.isfinite(a).all()
+    b, sb = ctx.render(rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9), cfg)
+    assert sb.kernel_used == rtow.KERNEL_BVH4
+    assert np.abs(a.mean(axis=(0, 1)) - b.mean(axis=(0, 1))).max() / 16 < 0.01
+
+
 def test_error_paths(ctx):
     L = rtow.lib()
     fresh = rtow.Context(0)
