@@ -20,10 +20,12 @@ pytestmark = pytest.mark.gpu
 def random_scene(seed, n_sph, n_mov, n_tri, keep):
     rng = np.random.default_rng(seed)
     base = rtow.HostScene.cover(0, 1.5, False)
-    sph = np.zeros((n_sph + 1, 4))
-    sph[0] = [0.0, -200.5, 0.0, 200.0]  # a big ground sphere among small ones
-    sph[1:, :3] = rng.uniform(-3, 3, size=(n_sph, 3)) * [1, 0.4, 1] + [0, 0.6, 0]
-    sph[1:, 3] = rng.choice([0.05, 0.15, 0.4, 0.9], size=n_sph, p=[0.4, 0.4, 0.15, 0.05])
+    g = 0 if (n_sph == 0 and n_mov == 0) else 1  # triangle-only scenes stay triangle-only (the BVH4 kernel's case)
+    sph = np.zeros((n_sph + g, 4))
+    if g:
+        sph[0] = [0.0, -200.5, 0.0, 200.0]  # a big ground sphere among small ones
+    sph[g:, :3] = rng.uniform(-3, 3, size=(n_sph, 3)) * [1, 0.4, 1] + [0, 0.6, 0]
+    sph[g:, 3] = rng.choice([0.05, 0.15, 0.4, 0.9], size=n_sph, p=[0.4, 0.4, 0.15, 0.05])
     mov = np.zeros((n_mov, 8))  # c0 xyz, c1 xyz, radius, pad
     mov[:, :3] = rng.uniform(-3, 3, size=(n_mov, 3)) * [1, 0.4, 1] + [0, 0.6, 0]
     mov[:, 3:6] = mov[:, :3] + rng.uniform(-0.4, 0.4, size=(n_mov, 3))
@@ -40,8 +42,8 @@ def random_scene(seed, n_sph, n_mov, n_tri, keep):
         mats[i].albedo = (C.c_double * 3)(*rng.uniform(0.3, 0.95, 3))
         mats[i].fuzz = float(rng.uniform(0, 0.5)) if kind == rtow.MAT_METAL else 0.0
         mats[i].ir = 1.5
-    ns, nm, nt = n_sph + 1, n_mov, n_tri
-    smat = rng.integers(0, n_mat, ns).astype(np.int32)
+    ns, nm, nt = n_sph + g, n_mov, n_tri
+    smat = rng.integers(0, n_mat, max(ns, 1)).astype(np.int32)
     smat[0] = 0  # Lambertian ground
     mmat = rng.integers(0, n_mat, max(nm, 1)).astype(np.int32)
     tmat = (rng.integers(0, n_mat // 3, max(nt, 1)) * 3).astype(np.int32)  # triangles: Lambertian only
@@ -66,7 +68,7 @@ def random_scene(seed, n_sph, n_mov, n_tri, keep):
     return sc
 
 
-SHAPES = [(30, 0, 0), (60, 20, 0), (0, 0, 80), (40, 10, 60), (200, 0, 0), (5, 5, 5), (120, 40, 100)]
+SHAPES = [(30, 0, 0), (60, 20, 0), (0, 0, 80), (40, 10, 60), (200, 0, 0), (5, 5, 5), (120, 40, 100), (0, 0, 1500)]
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"s{a}_m{b}_t{c}" for a, b, c in SHAPES])
@@ -79,9 +81,11 @@ def test_random_scene_all_kernels_and_builders_match_the_oracle(ctx, shape):
     dctx.set_builder(rtow.BUILDER_DEVICE_LBVH)
     try:
         for c in (ctx, dctx):
-            for kernel in (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_GRID):
+            for kernel in (rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_GRID, rtow.KERNEL_BVH4):  # (BVH4: triangle-only scenes, host builder; else the binary walk)
                 cfg = rtow.make_config(72, 48, 4, 2, 12, seed=shape[0] + 3, precision=rtow.F64_STRICT, kernel=kernel)
                 img, st = c.render(scene, cfg)
+                if kernel == rtow.KERNEL_BVH4 and c is ctx and shape[0] == 0 and shape[1] == 0:
+                    assert st.kernel_used == rtow.KERNEL_BVH4
                 assert st.segments == ost.segments, (kernel, st.kernel_used)
                 assert np.array_equal(img, ref), (kernel, st.kernel_used, int((img != ref).sum()))
             # the fast and f32 builds: finite, close, and the same from both builders
