@@ -205,6 +205,7 @@ struct Knobs {
   bool no_tiles = false;          // RTOW_NO_TILES
   int sky_eighths = 1;            // RTOW_SKY_EIGHTHS
   bool stamps = false;            // RTOW_STAMPS: diagnostic region-stamp build
+  bool bvh4_no_aux = false;       // RTOW_BVH4_NO_AUX: materials / material indices stay in L2 when only the top of the tree is staged
   bool no_bvh4 = false;           // RTOW_NO_BVH4: triangle meshes keep the binary threaded walk
   // Scheduling of the trip kernels (measured on one MI355X; 0 / "off" switches a measure off):
   int fetch_votes = 4;            // RTOW_FETCH_VOTES: lanes that must need a work item before the fetch block runs
@@ -234,6 +235,7 @@ struct Knobs {
     sky_eighths = std::min(std::max(geti("RTOW_SKY_EIGHTHS", 1), 0), 8);
     stamps = std::getenv("RTOW_STAMPS") != nullptr;
     no_bvh4 = std::getenv("RTOW_NO_BVH4") != nullptr;
+    bvh4_no_aux = std::getenv("RTOW_BVH4_NO_AUX") != nullptr;
     fetch_votes = std::min(std::max(geti("RTOW_FETCH_VOTES", 4), 1), 64);
     leaf_votes = std::min(std::max(geti("RTOW_LEAF_VOTES", 0), 0), 64);
     bvh4_sm = std::getenv("RTOW_BVH4_SM") != nullptr;
@@ -849,18 +851,29 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
     block = 1024;
     const uint32_t per_entry = 4u * (uint32_t)block;
     stack_bound = 3 * c->bvh4_depth + 1;
-    uint32_t K, staged;
+    uint32_t K, staged, aux_src = scene.blob4_bytes, aux_bytes = 0u;
     const uint32_t min_k = c->knobs.bvh4_stack_k > 0 ? (uint32_t)c->knobs.bvh4_stack_k : 8u;  // RTOW_BVH4_STACK_K
     if (scene.blob4_bytes + min_k * per_entry <= kLdsLimit) {
       staged = scene.blob4_bytes;
       K = std::min<uint32_t>((kLdsLimit - staged) / per_entry, 32u);
     } else {
       K = c->knobs.bvh4_stack_k > 0 ? std::min<uint32_t>((uint32_t)c->knobs.bvh4_stack_k, 32u) : 24u;
-      staged = std::min<uint32_t>((kLdsLimit - K * per_entry) / rtow::kBvh4NodeBytes * rtow::kBvh4NodeBytes, scene.b4_off_tri);
+      // the end of the image goes to LDS as well when it is small: materials + material indices, or the
+      // materials alone (shading reads index -> material after every hit: two dependent L2 round trips otherwise)
+      const uint32_t aux_max = c->knobs.bvh4_no_aux ? 0u : 16u * 1024u;
+      if (scene.blob4_bytes - scene.b4_off_pmat <= aux_max)
+        aux_src = scene.b4_off_pmat;
+      else if (scene.blob4_bytes - scene.b4_off_mats <= aux_max)
+        aux_src = scene.b4_off_mats;
+      aux_bytes = scene.blob4_bytes - aux_src;
+      staged = std::min<uint32_t>((kLdsLimit - K * per_entry - aux_bytes) / rtow::kBvh4NodeBytes * rtow::kBvh4NodeBytes,
+                                  scene.b4_off_tri);
     }
     K = std::min<uint32_t>(K, (uint32_t)stack_bound);
     scene.b4_lds_limit = staged;
-    scene.b4_stack_base = (staged + 15u) / 16u * 16u;
+    scene.b4_aux_src = aux_src;
+    scene.b4_aux_lds = (staged + 15u) / 16u * 16u;
+    scene.b4_stack_base = (scene.b4_aux_lds + aux_bytes + 15u) / 16u * 16u;
     scene.b4_stack_k = K;
     lds_bytes = scene.b4_stack_base + K * per_entry;
   }

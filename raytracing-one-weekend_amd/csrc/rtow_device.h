@@ -63,6 +63,9 @@ struct DevScene {
   uint32_t blob4_bytes;
   uint32_t b4_off_tri, b4_off_pmat, b4_off_mats;
   uint32_t b4_lds_limit;   // bytes of the image staged in LDS: all of it, or a 128-byte-aligned prefix of the nodes
+  // when only the top of the tree is staged: the END of the image from byte b4_aux_src on (the materials, and the
+  // material indices if they are small) is staged too, at LDS offset b4_aux_lds — shading reads them after every hit
+  uint32_t b4_aux_src, b4_aux_lds;
   uint32_t b4_stack_base;  // LDS byte offset of the traversal stack ([entry][lane of the workgroup], 4 B each)
   uint32_t b4_stack_k;     // entries per lane in LDS; deeper entries go to TraceParams::spill
 };

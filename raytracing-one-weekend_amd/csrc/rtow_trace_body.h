@@ -294,10 +294,18 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   if constexpr (KERNEL == 4) {
     im4.g = sc.blob4;
     im4.lds_limit = sc.b4_lds_limit;
+    im4.aux_src = sc.b4_aux_src;
+    im4.aux_lds = sc.b4_aux_lds;
     const uint4 *src = reinterpret_cast<const uint4 *>(sc.blob4);
     uint4 *dst = reinterpret_cast<uint4 *>(rtow_lds);
     const uint32_t n16 = sc.b4_lds_limit / 16u;
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    if (sc.b4_aux_src < sc.blob4_bytes) {  // the end of the image (materials, material indices): 16-byte aligned sections
+      const uint4 *asrc = reinterpret_cast<const uint4 *>(sc.blob4 + sc.b4_aux_src);
+      uint4 *adst = reinterpret_cast<uint4 *>(rtow_lds + sc.b4_aux_lds);
+      const uint32_t a16 = (sc.blob4_bytes - sc.b4_aux_src) / 16u;
+      for (uint32_t i = threadIdx.x; i < a16; i += blockDim.x) adst[i] = asrc[i];
+    }
     __syncthreads();
   } else if constexpr (KERNEL >= 2 && LDS) {
     // stage the scene image: coalesced 16-byte loads, 16-byte LDS stores
@@ -517,7 +525,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       if constexpr (KERNEL == 4) {
         // triangles only: the un-normalised normal e1 x e2 of the record (src/common-model.cpp:121)
         const uint32_t r = sc.b4_off_tri + 96u * (uint32_t)pid;
-        const vd2 q4 = im4.d2(r + 64u), q5 = im4.d2(r + 80u);
+        const vd2 q4 = im4.t2(r + 64u), q5 = im4.t2(r + 80u);
         normal = {(real)q4.y, (real)q5.x, (real)q5.y};
         mi = (int)im4.u32(sc.b4_off_pmat + 4u * (uint32_t)pid);
         const uint32_t mr = sc.b4_off_mats + 48u * (uint32_t)mi;

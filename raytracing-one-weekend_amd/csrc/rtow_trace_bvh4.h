@@ -55,13 +55,26 @@ template <bool FULL>
 struct Bvh4Reader {
   const unsigned char *g;  // the image in global memory
   uint32_t lds_limit;      // bytes of it staged at the start of LDS
+  uint32_t aux_src, aux_lds;  // the image's end [aux_src, ...) staged at LDS offset aux_lds (wave-uniform)
   template <class T>
-  __device__ __forceinline__ T rec(uint32_t off) const {  // triangle records, material indices, materials
+  __device__ __forceinline__ T tri(uint32_t off) const {  // triangle records (the leaf loop: no residency test)
     if constexpr (FULL)
       return lds_read<T>(off);
     else
       return glb_read<T>(g, off);
   }
+  template <class T>
+  __device__ __forceinline__ T rec(uint32_t off) const {  // material indices, materials (shading)
+    if constexpr (FULL) {
+      return lds_read<T>(off);
+    } else {
+      // (material indices and materials are staged as a block or not at all, so the side taken is the same for
+      // every lane at a given call site)
+      if (off >= aux_src) return lds_read<T>(aux_lds + (off - aux_src));
+      return glb_read<T>(g, off);
+    }
+  }
+  __device__ __forceinline__ vd2 t2(uint32_t off) const { return tri<vd2>(off); }
   __device__ __forceinline__ vd2 d2(uint32_t off) const { return rec<vd2>(off); }
   __device__ __forceinline__ uint32_t u32(uint32_t off) const { return rec<uint32_t>(off); }
 };
@@ -188,8 +201,8 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
         const uint32_t first = (q0 & (kRefLeaf - 1u)) >> 2, count = (q0 & 3u) + 1u;
         for (uint32_t k = 0; k < count; ++k) {
           const uint32_t r = sc.b4_off_tri + 96u * (first + k);
-          const vd2 t0 = im.d2(r), t1 = im.d2(r + 16u), t2 = im.d2(r + 32u), t3 = im.d2(r + 48u), t4 = im.d2(r + 64u),
-                        t5 = im.d2(r + 80u);
+          const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u), t4 = im.t2(r + 64u),
+                        t5 = im.t2(r + 80u);
           ++nprim;
           triangle_test<double>(ray.o64, ray.d64, V3d{t0.x, t0.y, t1.x}, V3d{t1.y, t2.x, t2.y}, V3d{t3.x, t3.y, t4.x},
                                 V3d{t4.y, t5.x, t5.y}, (int)(first + k), RTOW_TMIN, best);
@@ -201,8 +214,8 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
         const uint32_t first = (q0 & (kRefLeaf - 1u)) >> 2, count = (q0 & 3u) + 1u;
         for (uint32_t k = 0; k < count; ++k) {
           const uint32_t r = sc.b4_off_tri + 96u * (first + k);
-          const vd2 t0 = im.d2(r), t1 = im.d2(r + 16u), t2 = im.d2(r + 32u), t3 = im.d2(r + 48u), t4 = im.d2(r + 64u),
-                    t5 = im.d2(r + 80u);
+          const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u), t4 = im.t2(r + 64u),
+                    t5 = im.t2(r + 80u);
           ++nprim;
           triangle_test<double>(ray.o64, ray.d64, V3d{t0.x, t0.y, t1.x}, V3d{t1.y, t2.x, t2.y}, V3d{t3.x, t3.y, t4.x},
                                 V3d{t4.y, t5.x, t5.y}, (int)(first + k), RTOW_TMIN, best);

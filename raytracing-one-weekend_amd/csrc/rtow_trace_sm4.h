@@ -38,11 +38,19 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
   Bvh4Reader<FULL> im;
   im.g = sc.blob4;
   im.lds_limit = sc.b4_lds_limit;
+  im.aux_src = sc.b4_aux_src;
+  im.aux_lds = sc.b4_aux_lds;
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(sc.blob4);
     uint4 *dst = reinterpret_cast<uint4 *>(rtow_lds);
     const uint32_t n16 = sc.b4_lds_limit / 16u;
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    if (sc.b4_aux_src < sc.blob4_bytes) {  // the end of the image (materials, material indices)
+      const uint4 *asrc = reinterpret_cast<const uint4 *>(sc.blob4 + sc.b4_aux_src);
+      uint4 *adst = reinterpret_cast<uint4 *>(rtow_lds + sc.b4_aux_lds);
+      const uint32_t a16 = (sc.blob4_bytes - sc.b4_aux_src) / 16u;
+      for (uint32_t i = threadIdx.x; i < a16; i += blockDim.x) adst[i] = asrc[i];
+    }
     __syncthreads();
   }
 
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
             const int pid = best.prim;
             const V3 where = ro + rd * best.t;
             const uint32_t r = sc.b4_off_tri + 96u * (uint32_t)pid;
-            const vd2 q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
+            const vd2 q4 = im.t2(r + 64u), q5 = im.t2(r + 80u);
             const V3 normal = {(real)q4.y, (real)q5.x, (real)q5.y};
             const int mi = (int)im.u32(sc.b4_off_pmat + 4u * (uint32_t)pid);
             const uint32_t mr = sc.b4_off_mats + 48u * (uint32_t)mi;
@@ -300,8 +308,8 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
           const V3d o64 = to_f64(ro), d64 = to_f64(rd);
           for (uint32_t k = 0; k < count; ++k) {
             const uint32_t r = sc.b4_off_tri + 96u * (first + k);
-            const vd2 t0 = im.d2(r), t1 = im.d2(r + 16u), t2 = im.d2(r + 32u), t3 = im.d2(r + 48u), t4 = im.d2(r + 64u),
-                      t5 = im.d2(r + 80u);
+            const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u), t4 = im.t2(r + 64u),
+                      t5 = im.t2(r + 80u);
             ++nprim;
             triangle_test<double>(o64, d64, V3d{t0.x, t0.y, t1.x}, V3d{t1.y, t2.x, t2.y}, V3d{t3.x, t3.y, t4.x},
                                   V3d{t4.y, t5.x, t5.y}, (int)(first + k), RTOW_TMIN, best);
