@@ -626,13 +626,6 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
       g.r += 1u;
     }
-#ifdef RTOW_EXTRA_PHILOX  // timing experiment only: what one more block evaluation per trip costs
-    if (do_regen || do_scat) {
-      uint32_t x0, x1, x2, x3;
-      philox4x32(g.r + 77u, g.sample, g.pixel, 1u, k0, k1, x0, x1, x2, x3);
-      if (x0 == 0x12345678u && x1 == 0x9abcdefu && x2 == x3) o0 ^= 1u;
-    }
-#endif
     if constexpr (STAMPS) {  // wave-level count of block evaluations: the first active lane reports
       if ((do_regen || do_scat) && (int)lane == __ffsll((long long)__ballot(do_regen || do_scat)) - 1)
         atomicAdd(&P.counters[44], 1ull);
