@@ -79,6 +79,132 @@ struct Bvh4Reader {
   __device__ __forceinline__ uint32_t u32(uint32_t off) const { return rec<uint32_t>(off); }
 };
 
+// ---- the pieces of the walk, shared by the trip-structured kernel below and the state machine (rtow_trace_sm4.h) ----
+// The f32 forms of a ray the slab tests need.
+struct Bvh4Ray {
+  float ix, iy, iz, oix, oiy, oiz;  // 1/d (huge if d is 0) and o/d: t(plane) = plane * ix - oix
+  uint32_t nxo, nyo, nzo;           // where this ray finds the NEAR planes of a node (the far planes: address ^ 16)
+};
+__device__ __forceinline__ Bvh4Ray bvh4_ray(V3 o, V3 d) {
+  Bvh4Ray r;
+  r.ix = safe_inv((float)d.x), r.iy = safe_inv((float)d.y), r.iz = safe_inv((float)d.z);
+  r.oix = (float)o.x * r.ix, r.oiy = (float)o.y * r.iy, r.oiz = (float)o.z * r.iz;
+  r.nxo = r.ix < 0.0f ? 16u : 0u, r.nyo = r.iy < 0.0f ? 48u : 32u, r.nzo = r.iz < 0.0f ? 80u : 64u;
+  return r;
+}
+// This lane's traversal stack: LDS slot s at lds + s * kBvh4StackStride (workgroups are 1024 lanes); slots at or
+// beyond `end` live in the global spill array [entry][lane of the grid].
+constexpr uint32_t kBvh4StackStrideLog2 = 12u, kBvh4StackStride = 1u << kBvh4StackStrideLog2;
+struct Bvh4Stack {
+  uint32_t lds, end;
+};
+__device__ __forceinline__ Bvh4Stack bvh4_stack(const DevScene &sc) {
+  Bvh4Stack st;
+  st.lds = sc.b4_stack_base + 4u * threadIdx.x;
+  st.end = st.lds + (sc.b4_stack_k << kBvh4StackStrideLog2);
+  return st;
+}
+
+// One step of one lane.  `cur` is the node or leaf in hand (kRefPop: take the next stack entry; kRefNone: nothing
+// left but the queued leaves), `sa` the address of the next free stack slot, (q0, q1) the queued leaves, oldest
+// first, `tmax32` the closest hit so far rounded up to f32.
+template <bool FULL>
+__device__ __forceinline__ void bvh4_step(const Bvh4Reader<FULL> &im, const TraceParams &P, const Bvh4Ray &r, float tmax32,
+                                          Bvh4Stack st, uint32_t lane_g, uint32_t &cur, uint32_t &sa, uint32_t &q0,
+                                          uint32_t &q1, uint32_t &nnode) {
+  const float tmin32 = 0.0009f;  // < RTOW_TMIN
+  const float slack = 1.00002f;  // relative slack on the far side of the interval
+  // (1) a leaf reached by the walk waits in the queue for the next leaf phase
+  if ((cur & kRefLeaf) != 0u && cur < kRefPop && q1 == kRefNone) {
+    if (q0 == kRefNone)
+      q0 = cur;
+    else
+      q1 = cur;
+    cur = kRefPop;
+  }
+  // (2) next entry from the stack; an entry that starts beyond the closest hit so far is dropped
+  if (cur == kRefPop) {
+    if (sa == st.lds) {
+      cur = kRefNone;
+    } else {
+      sa -= kBvh4StackStride;
+      uint32_t e;
+      if (sa < st.end)
+        e = lds_read<uint32_t>(sa);
+      else
+        e = P.spill[(size_t)((sa - st.end) >> kBvh4StackStrideLog2) * P.n_lanes + lane_g];
+      cur = (e >> 21) > (__float_as_uint(tmax32) >> 20) ? kRefPop : (e & 0x1fffffu);
+    }
+  }
+  // (3) one node: four slab tests, nearest hit child next, the others to the stack
+  if (cur < kRefLeaf) {
+    const uint32_t nb = cur * kBvh4NodeBytes;
+    vf4 nx, fx, ny, fy, nz, fz;
+    vu4 cw;
+    if (FULL || nb < im.lds_limit) {
+      nx = lds_read<vf4>(nb + r.nxo), fx = lds_read<vf4>((nb + r.nxo) ^ 16u);
+      ny = lds_read<vf4>(nb + r.nyo), fy = lds_read<vf4>((nb + r.nyo) ^ 16u);
+      nz = lds_read<vf4>(nb + r.nzo), fz = lds_read<vf4>((nb + r.nzo) ^ 16u);
+      cw = lds_read<vu4>(nb + 96u);
+    } else {
+      nx = glb_read<vf4>(im.g, nb + r.nxo), fx = glb_read<vf4>(im.g, (nb + r.nxo) ^ 16u);
+      ny = glb_read<vf4>(im.g, nb + r.nyo), fy = glb_read<vf4>(im.g, (nb + r.nyo) ^ 16u);
+      nz = glb_read<vf4>(im.g, nb + r.nzo), fz = glb_read<vf4>(im.g, (nb + r.nzo) ^ 16u);
+      cw = glb_read<vu4>(im.g, nb + 96u);
+    }
+    ++nnode;
+#define RTOW_SLAB(c, slot)                                                                                             \
+  const float tn##slot =                                                                                               \
+      fmaxf(fmaxf(fmaf(nx.c, r.ix, -r.oix), fmaf(ny.c, r.iy, -r.oiy)), fmaxf(fmaf(nz.c, r.iz, -r.oiz), tmin32));       \
+  const float tf##slot =                                                                                               \
+      fminf(fminf(fmaf(fx.c, r.ix, -r.oix), fmaf(fy.c, r.iy, -r.oiy)), fminf(fmaf(fz.c, r.iz, -r.oiz), tmax32));       \
+  const bool h##slot = tn##slot <= tf##slot * slack;                                                                   \
+  const uint32_t k##slot = h##slot ? ((__float_as_uint(tn##slot) & ~3u) | slot##u) : 0xffffffffu;
+    RTOW_SLAB(x, 0)
+    RTOW_SLAB(y, 1)
+    RTOW_SLAB(z, 2)
+    RTOW_SLAB(w, 3)
+#undef RTOW_SLAB
+    const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+    const uint32_t s = kmin & 3u;  // (3 when nothing was hit: h3 is false then, nothing is pushed)
+    const uint32_t next = s == 0u ? cw.x : (s == 1u ? cw.y : (s == 2u ? cw.z : cw.w));
+    cur = kmin == 0xffffffffu ? kRefPop : next;
+#define RTOW_PUSH(slot, child)                                                                       \
+  if (h##slot && s != slot##u) {                                                                     \
+    const uint32_t e = ((__float_as_uint(tn##slot) >> 20) << 21) | child;                            \
+    if (sa < st.end)                                                                                 \
+      lds_write<uint32_t>(sa, e);                                                                    \
+    else                                                                                             \
+      P.spill[(size_t)((sa - st.end) >> kBvh4StackStrideLog2) * P.n_lanes + lane_g] = e;             \
+    sa += kBvh4StackStride;                                                                          \
+  }
+    RTOW_PUSH(0, cw.x)
+    RTOW_PUSH(1, cw.y)
+    RTOW_PUSH(2, cw.z)
+    RTOW_PUSH(3, cw.w)
+#undef RTOW_PUSH
+  }
+}
+
+// The triangles of one queued leaf, with the f64 test every kernel uses (so the accepted (t, primitive) is the same).
+template <bool FULL>
+__device__ __forceinline__ void bvh4_leaf(const Bvh4Reader<FULL> &im, const DevScene &sc, uint32_t leaf, V3d o64, V3d d64,
+                                          Closest &best, uint32_t &nprim) {
+  const uint32_t first = (leaf & (kRefLeaf - 1u)) >> 2, count = (leaf & 3u) + 1u;
+  for (uint32_t k = 0; k < count; ++k) {
+    const uint32_t r = sc.b4_off_tri + 96u * (first + k);
+    const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u), t4 = im.t2(r + 64u),
+              t5 = im.t2(r + 80u);
+    ++nprim;
+    triangle_test<double>(o64, d64, V3d{t0.x, t0.y, t1.x}, V3d{t1.y, t2.x, t2.y}, V3d{t3.x, t3.y, t4.x}, V3d{t4.y, t5.x, t5.y},
+                          (int)(first + k), RTOW_TMIN, best);
+  }
+}
+// a lane that can take a step (it holds a node, a stack to pop, or a leaf that still fits its queue)
+__device__ __forceinline__ bool bvh4_busy(uint32_t cur, uint32_t q1) {
+  return cur != kRefNone && !((cur & kRefLeaf) != 0u && cur < kRefPop && q1 != kRefNone);
+}
+
 // Resumable like the grid walk (rtow_trace_grid.h): after `cap` loop trips with at most `max_open`
 // lanes still walking, the queued leaves are tested and the unfinished lanes keep their place — the
 // node in hand (`w_cur`, kRefNone = no walk in progress), the stack (it lives in LDS / the spill
@@ -88,142 +214,43 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
                                                     V3 o, V3 d, real time, bool active, uint32_t lane_g, uint32_t &nnode,
                                                     uint32_t &nprim, Stamps<ST> &stamps, Closest best, uint32_t &w_cur,
                                                     uint32_t &w_sa, uint32_t cap, uint32_t max_open) {
+  (void)time;  // triangles do not move
   const bool resumed = w_cur != kRefNone;
   if (!resumed) {
     best.t = (real)__builtin_huge_val();
     best.prim = -1;
   }
-  const RayForms ray = make_ray_forms(o, d, time);
-  const float tmin32 = 0.0009f;   // < RTOW_TMIN
-  const float slack = 1.00002f;   // relative slack on the far side of the interval, folded into the far-plane terms
-  const float ix = safe_inv((float)d.x), iy = safe_inv((float)d.y), iz = safe_inv((float)d.z);
-  const float oix = (float)o.x * ix, oiy = (float)o.y * iy, oiz = (float)o.z * iz;
-  const float jx = ix * slack, jy = iy * slack, jz = iz * slack;
-  const float ojx = oix * slack, ojy = oiy * slack, ojz = oiz * slack;
+  const V3d o64 = to_f64(o), d64 = to_f64(d);
+  const Bvh4Ray ray = bvh4_ray(o, d);
+  const Bvh4Stack st = bvh4_stack(sc);
   float tmax32 = round_up_f32(best.t);  // closest hit so far, rounded up
-  float tfm = tmax32 * slack;           // ... times slack
-  // where this ray finds the near planes of a node (the far planes are at the same address ^ 16)
-  const uint32_t nxo = ix < 0.0f ? 16u : 0u, nyo = iy < 0.0f ? 48u : 32u, nzo = iz < 0.0f ? 80u : 64u;
-  // the stack: LDS slot s of this lane at stack_lds + s * kStride (workgroups are 1024 lanes); `sa` is the
-  // address of the next free slot, slots at or beyond `sa_end` live in the global spill array
-  constexpr uint32_t kStrideLog2 = 12u, kStride = 1u << kStrideLog2;
-  const uint32_t stack_lds = sc.b4_stack_base + 4u * threadIdx.x;
-  const uint32_t sa_end = stack_lds + (sc.b4_stack_k << kStrideLog2);
-  uint32_t sa = resumed ? w_sa : stack_lds;
+  uint32_t sa = resumed ? w_sa : st.lds;
   uint32_t cur = !active ? kRefNone : (resumed ? w_cur : 0u);  // node 0 = root
   uint32_t q0 = kRefNone, q1 = kRefNone;  // queued leaves, oldest first
   uint32_t trips = 0u;                    // wave-uniform
 
   for (;;) {
     if constexpr (ST) stamps.iters += 1;
-    // (1) a leaf reached by the walk waits in the queue for the next leaf phase
-    if ((cur & kRefLeaf) != 0u && cur < kRefPop && q1 == kRefNone) {
-      if (q0 == kRefNone)
-        q0 = cur;
-      else
-        q1 = cur;
-      cur = kRefPop;
-    }
-    // (2) next entry from the stack; an entry that starts beyond the closest hit so far is dropped
-    if (cur == kRefPop) {
-      if (sa == stack_lds) {
-        cur = kRefNone;
-      } else {
-        sa -= kStride;
-        uint32_t e;
-        if (sa < sa_end)
-          e = lds_read<uint32_t>(sa);
-        else
-          e = P.spill[(size_t)((sa - sa_end) >> kStrideLog2) * P.n_lanes + lane_g];
-        cur = (e >> 21) > (__float_as_uint(tmax32) >> 20) ? kRefPop : (e & 0x1fffffu);
-      }
-    }
-    // (3) one node: four slab tests, nearest hit child next, the others to the stack
-    if (cur < kRefLeaf) {
-      const uint32_t nb = cur * kBvh4NodeBytes;
-      vf4 nx, fx, ny, fy, nz, fz;
-      vu4 cw;
-      if (FULL || nb < im.lds_limit) {
-        nx = lds_read<vf4>(nb + nxo), fx = lds_read<vf4>((nb + nxo) ^ 16u);
-        ny = lds_read<vf4>(nb + nyo), fy = lds_read<vf4>((nb + nyo) ^ 16u);
-        nz = lds_read<vf4>(nb + nzo), fz = lds_read<vf4>((nb + nzo) ^ 16u);
-        cw = lds_read<vu4>(nb + 96u);
-      } else {
-        nx = glb_read<vf4>(im.g, nb + nxo), fx = glb_read<vf4>(im.g, (nb + nxo) ^ 16u);
-        ny = glb_read<vf4>(im.g, nb + nyo), fy = glb_read<vf4>(im.g, (nb + nyo) ^ 16u);
-        nz = glb_read<vf4>(im.g, nb + nzo), fz = glb_read<vf4>(im.g, (nb + nzo) ^ 16u);
-        cw = glb_read<vu4>(im.g, nb + 96u);
-      }
-      ++nnode;
-#define RTOW_SLAB(c, slot)                                                                                   \
-  const float tn##slot = fmaxf(fmaxf(fmaf(nx.c, ix, -oix), fmaf(ny.c, iy, -oiy)), fmaxf(fmaf(nz.c, iz, -oiz), tmin32)); \
-  const float tf##slot = fminf(fminf(fmaf(fx.c, jx, -ojx), fmaf(fy.c, jy, -ojy)), fminf(fmaf(fz.c, jz, -ojz), tfm));    \
-  const bool h##slot = tn##slot <= tf##slot;                                                                 \
-  const uint32_t k##slot = h##slot ? ((__float_as_uint(tn##slot) & ~3u) | slot##u) : 0xffffffffu;
-      RTOW_SLAB(x, 0)
-      RTOW_SLAB(y, 1)
-      RTOW_SLAB(z, 2)
-      RTOW_SLAB(w, 3)
-#undef RTOW_SLAB
-      const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-      const uint32_t s = kmin & 3u;  // (3 when nothing was hit: h3 is false then, nothing is pushed)
-      const uint32_t next = s == 0u ? cw.x : (s == 1u ? cw.y : (s == 2u ? cw.z : cw.w));
-      cur = kmin == 0xffffffffu ? kRefPop : next;
-#define RTOW_PUSH(slot, child)                                                                         \
-  if (h##slot && s != slot##u) {                                                                       \
-    const uint32_t e = ((__float_as_uint(tn##slot) >> 20) << 21) | child;                              \
-    if (sa < sa_end)                                                                                   \
-      lds_write<uint32_t>(sa, e);                                                                      \
-    else                                                                                               \
-      P.spill[(size_t)((sa - sa_end) >> kStrideLog2) * P.n_lanes + lane_g] = e;                        \
-    sa += kStride;                                                                                     \
-  }
-      RTOW_PUSH(0, cw.x)
-      RTOW_PUSH(1, cw.y)
-      RTOW_PUSH(2, cw.z)
-      RTOW_PUSH(3, cw.w)
-#undef RTOW_PUSH
-    }
+    bvh4_step<FULL>(im, P, ray, tmax32, st, lane_g, cur, sa, q0, q1, nnode);
     const unsigned long long m_walking = __ballot(cur != kRefNone);
     const bool any_walking = m_walking != 0ull;
     ++trips;
     const bool suspend = any_walking && trips >= cap && (uint32_t)__popcll(m_walking) <= max_open;
-    // leaf phase: when enough lanes hold a queued leaf, or when no lane can take a node step (every
-    // walking lane holds a leaf it cannot queue), or at the end
-    const bool busy = cur != kRefNone && !((cur & kRefLeaf) != 0u && cur < kRefPop && q1 != kRefNone);
+    // leaf phase: when enough lanes hold a queued leaf, or when no lane can take a step, or at the end
     const unsigned long long m_pending = __ballot(q0 != kRefNone);
-    if ((m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= P.leaf_votes || __ballot(busy) == 0ull)) || !any_walking ||
-        suspend) {
+    if ((m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= P.leaf_votes || __ballot(bvh4_busy(cur, q1)) == 0ull)) ||
+        !any_walking || suspend) {
       stamps.mark(RG_WALK);
       if constexpr (ST) stamps.phases += 1;
-      // leaf phase: every lane tests the triangles of the OLDEST leaf it queued
-      if (q0 != kRefNone) {
-        const uint32_t first = (q0 & (kRefLeaf - 1u)) >> 2, count = (q0 & 3u) + 1u;
-        for (uint32_t k = 0; k < count; ++k) {
-          const uint32_t r = sc.b4_off_tri + 96u * (first + k);
-          const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u), t4 = im.t2(r + 64u),
-                        t5 = im.t2(r + 80u);
-          ++nprim;
-          triangle_test<double>(ray.o64, ray.d64, V3d{t0.x, t0.y, t1.x}, V3d{t1.y, t2.x, t2.y}, V3d{t3.x, t3.y, t4.x},
-                                V3d{t4.y, t5.x, t5.y}, (int)(first + k), RTOW_TMIN, best);
-        }
-      }
+      // every lane tests the triangles of the OLDEST leaf it queued
+      if (q0 != kRefNone) bvh4_leaf<FULL>(im, sc, q0, o64, d64, best, nprim);
       q0 = q1;
       q1 = kRefNone;
       if (suspend && q0 != kRefNone) {  // both queued leaves before stopping
-        const uint32_t first = (q0 & (kRefLeaf - 1u)) >> 2, count = (q0 & 3u) + 1u;
-        for (uint32_t k = 0; k < count; ++k) {
-          const uint32_t r = sc.b4_off_tri + 96u * (first + k);
-          const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u), t4 = im.t2(r + 64u),
-                    t5 = im.t2(r + 80u);
-          ++nprim;
-          triangle_test<double>(ray.o64, ray.d64, V3d{t0.x, t0.y, t1.x}, V3d{t1.y, t2.x, t2.y}, V3d{t3.x, t3.y, t4.x},
-                                V3d{t4.y, t5.x, t5.y}, (int)(first + k), RTOW_TMIN, best);
-        }
+        bvh4_leaf<FULL>(im, sc, q0, o64, d64, best, nprim);
         q0 = kRefNone;
       }
       tmax32 = round_up_f32(best.t);  // rounded up: never below the f64 value
-      tfm = tmax32 * slack;
       stamps.mark(RG_LEAF);
       if (suspend) {
         w_cur = cur;  // kRefNone for the lanes that are done

@@ -77,16 +77,11 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
     if (lane == 0) atomicMin(P.t_origin, (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
 
-  // ---- walk state (live for the lanes in PH_WALK) -------------------------------------------
-  constexpr uint32_t kStrideLog2 = 12u, kStride = 1u << kStrideLog2;
-  const uint32_t stack_lds = sc.b4_stack_base + 4u * threadIdx.x;
-  const uint32_t sa_end = stack_lds + (sc.b4_stack_k << kStrideLog2);
-  const float tmin32 = 0.0009f;  // < RTOW_TMIN
-  const float slack = 1.00002f;  // relative slack on the far side of the interval
-  float ix = 0, iy = 0, iz = 0, oix = 0, oiy = 0, oiz = 0;
-  uint32_t nxo = 0, nyo = 32u, nzo = 64u;
+  // ---- walk state (live for the lanes in PH_WALK; rtow_trace_bvh4.h) ------------------------------
+  const Bvh4Stack stk = bvh4_stack(sc);
+  Bvh4Ray ray = bvh4_ray(ro, rd);
   float tmax32 = 0;
-  uint32_t sa = stack_lds;
+  uint32_t sa = stk.lds;
   uint32_t cur = kRefNone, q0 = kRefNone, q1 = kRefNone;
   Closest best;
   best.t = 0;
@@ -210,11 +205,9 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
     stamps.mark(RG_SHADE);
     // ---- walk start --------------------------------------------------------------------------
     if (phase == PH_START) {
-      ix = safe_inv((float)rd.x), iy = safe_inv((float)rd.y), iz = safe_inv((float)rd.z);
-      oix = (float)ro.x * ix, oiy = (float)ro.y * iy, oiz = (float)ro.z * iz;
-      nxo = ix < 0.0f ? 16u : 0u, nyo = iy < 0.0f ? 48u : 32u, nzo = iz < 0.0f ? 80u : 64u;
+      ray = bvh4_ray(ro, rd);
       tmax32 = __builtin_huge_valf();
-      sa = stack_lds;
+      sa = stk.lds;
       cur = 0u;  // the root
       q0 = q1 = kRefNone;
       best.t = (real)__builtin_huge_val();
@@ -226,94 +219,16 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
     const bool walking = phase == PH_WALK;
     if (__ballot(walking) != 0ull) {
       if constexpr (STAMPS) stamps.iters += 1;
-      // (1) a leaf reached by the walk waits in the queue for the next leaf phase
-      if (walking && (cur & kRefLeaf) != 0u && cur < kRefPop && q1 == kRefNone) {
-        if (q0 == kRefNone)
-          q0 = cur;
-        else
-          q1 = cur;
-        cur = kRefPop;
-      }
-      // (2) next entry from the stack; an entry that starts beyond the closest hit so far is dropped
-      if (walking && cur == kRefPop) {
-        if (sa == stack_lds) {
-          cur = kRefNone;
-        } else {
-          sa -= kStride;
-          uint32_t e;
-          if (sa < sa_end)
-            e = lds_read<uint32_t>(sa);
-          else
-            e = P.spill[(size_t)((sa - sa_end) >> kStrideLog2) * P.n_lanes + lane_g];
-          cur = (e >> 21) > (__float_as_uint(tmax32) >> 20) ? kRefPop : (e & 0x1fffffu);
-        }
-      }
-      // (3) one node: four slab tests, nearest hit child next, the others to the stack
-      if (walking && cur < kRefLeaf) {
-        const uint32_t nbase = cur * kBvh4NodeBytes;
-        vf4 nx, fx, ny, fy, nz, fz;
-        vu4 cw;
-        if (FULL || nbase < im.lds_limit) {
-          nx = lds_read<vf4>(nbase + nxo), fx = lds_read<vf4>((nbase + nxo) ^ 16u);
-          ny = lds_read<vf4>(nbase + nyo), fy = lds_read<vf4>((nbase + nyo) ^ 16u);
-          nz = lds_read<vf4>(nbase + nzo), fz = lds_read<vf4>((nbase + nzo) ^ 16u);
-          cw = lds_read<vu4>(nbase + 96u);
-        } else {
-          nx = glb_read<vf4>(im.g, nbase + nxo), fx = glb_read<vf4>(im.g, (nbase + nxo) ^ 16u);
-          ny = glb_read<vf4>(im.g, nbase + nyo), fy = glb_read<vf4>(im.g, (nbase + nyo) ^ 16u);
-          nz = glb_read<vf4>(im.g, nbase + nzo), fz = glb_read<vf4>(im.g, (nbase + nzo) ^ 16u);
-          cw = glb_read<vu4>(im.g, nbase + 96u);
-        }
-        ++nnode;
-        const float tfm = tmax32;
-#define RTOW_SLAB(c, slot)                                                                                   \
-  const float tn##slot = fmaxf(fmaxf(fmaf(nx.c, ix, -oix), fmaf(ny.c, iy, -oiy)), fmaxf(fmaf(nz.c, iz, -oiz), tmin32)); \
-  const float tf##slot = fminf(fminf(fmaf(fx.c, ix, -oix), fmaf(fy.c, iy, -oiy)), fminf(fmaf(fz.c, iz, -oiz), tfm));    \
-  const bool h##slot = tn##slot <= tf##slot * slack;                                                         \
-  const uint32_t k##slot = h##slot ? ((__float_as_uint(tn##slot) & ~3u) | slot##u) : 0xffffffffu;
-        RTOW_SLAB(x, 0)
-        RTOW_SLAB(y, 1)
-        RTOW_SLAB(z, 2)
-        RTOW_SLAB(w, 3)
-#undef RTOW_SLAB
-        const uint32_t kmin = min(min(k0, k1), min(k2, k3));
-        const uint32_t s = kmin & 3u;  // (3 when nothing was hit: h3 is false then, nothing is pushed)
-        const uint32_t next = s == 0u ? cw.x : (s == 1u ? cw.y : (s == 2u ? cw.z : cw.w));
-        cur = kmin == 0xffffffffu ? kRefPop : next;
-#define RTOW_PUSH(slot, child)                                                                         \
-  if (h##slot && s != slot##u) {                                                                       \
-    const uint32_t e = ((__float_as_uint(tn##slot) >> 20) << 21) | child;                              \
-    if (sa < sa_end)                                                                                   \
-      lds_write<uint32_t>(sa, e);                                                                      \
-    else                                                                                               \
-      P.spill[(size_t)((sa - sa_end) >> kStrideLog2) * P.n_lanes + lane_g] = e;                        \
-    sa += kStride;                                                                                     \
-  }
-        RTOW_PUSH(0, cw.x)
-        RTOW_PUSH(1, cw.y)
-        RTOW_PUSH(2, cw.z)
-        RTOW_PUSH(3, cw.w)
-#undef RTOW_PUSH
-      }
+      if (walking) bvh4_step<FULL>(im, P, ray, tmax32, stk, lane_g, cur, sa, q0, q1, nnode);
       stamps.mark(RG_WALK);
-      // Leaf phase: when enough lanes hold a queued leaf, or when no lane can take a node step (every
+      // Leaf phase: when enough lanes hold a queued leaf, or when no lane can take a step (every
       // walking lane either has nothing in hand or holds a leaf it cannot queue).
       const bool pending = walking && q0 != kRefNone;
-      const bool busy = walking && cur != kRefNone && !((cur & kRefLeaf) != 0u && cur < kRefPop && q1 != kRefNone);
       const unsigned long long m_pending = __ballot(pending);
-      if (m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= kLeafVotes || __ballot(busy) == 0ull)) {
+      if (m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= kLeafVotes || __ballot(walking && bvh4_busy(cur, q1)) == 0ull)) {
         if constexpr (STAMPS) stamps.phases += 1;
-        if (walking && q0 != kRefNone) {
-          const uint32_t first = (q0 & (kRefLeaf - 1u)) >> 2, count = (q0 & 3u) + 1u;
-          const V3d o64 = to_f64(ro), d64 = to_f64(rd);
-          for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t r = sc.b4_off_tri + 96u * (first + k);
-            const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u), t4 = im.t2(r + 64u),
-                      t5 = im.t2(r + 80u);
-            ++nprim;
-            triangle_test<double>(o64, d64, V3d{t0.x, t0.y, t1.x}, V3d{t1.y, t2.x, t2.y}, V3d{t3.x, t3.y, t4.x},
-                                  V3d{t4.y, t5.x, t5.y}, (int)(first + k), RTOW_TMIN, best);
-          }
+        if (pending) {
+          bvh4_leaf<FULL>(im, sc, q0, to_f64(ro), to_f64(rd), best, nprim);
           q0 = q1;
           q1 = kRefNone;
           tmax32 = round_up_f32(best.t);  // rounded up: never below the f64 value
