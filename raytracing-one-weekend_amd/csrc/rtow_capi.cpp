@@ -490,6 +490,8 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     rtow::HostBvh bvh;
     const double c_trav = c->knobs.bvh_ct;
     rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
+    std::vector<int32_t> prim_order;  // the tree's primitive order before the leaf-order pass renumbers it (for the 4-wide image)
+    if (ns == 0 && nm == 0 && !c->knobs.no_bvh4 && leaf_max <= 4) prim_order = bvh.prim;
     if (ns == 0 && nm == 0 && !c->knobs.no_leaf_order) {
       // Triangle meshes: the image holds the triangle records and their material indices in LEAF order
       // and the id list is the identity, so a leaf test reads its records directly instead of id ->
@@ -513,10 +515,11 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     // triangle meshes: the 4-wide tree collapsed from the same SAH tree (rtow_bvh4.h)
     c->have_bvh4 = false;
     if (ns == 0 && nm == 0 && !c->knobs.no_bvh4) {
-      rtow::HostBvh bvh2;  // built again: the leaf-order pass above renumbered bvh.prim
-      rtow::build_bvh(sph, sph_r, mov, tri, bvh2, std::min(leaf_max, 4), c_trav, s->camera.t0, s->camera.t1);
       rtow::Bvh4Image img4;
-      rtow::make_bvh4_image(bvh2, tri, pmat, mats_bytes, s->camera.origin, img4);
+      if (!prim_order.empty()) {  // the same SAH tree, collapsed (leaves of at most 4 triangles)
+        bvh.prim = prim_order;
+        rtow::make_bvh4_image(bvh, tri, pmat, mats_bytes, s->camera.origin, img4);
+      }
       if (img4.ok) {
         if (!rtow::validate_bvh4_image(img4, (size_t)nt))
           return fail(RTOW_EINVAL, "internal error: 4-wide scene image failed validation");
