@@ -17,9 +17,11 @@
 // camera first) and emits the 32-byte threaded node records of rtow_device.h.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <future>
 #include <vector>
 
 namespace rtow {
@@ -59,6 +61,14 @@ struct Builder {
   std::vector<double> cen;    // centroids [n][3]
   std::vector<int32_t> order; // permutation being partitioned
   HostBvh *out;
+  // Big subtrees are built concurrently (the two children of a node are independent: they partition disjoint
+  // ranges of `order`, node pairs come from an atomic counter into preallocated arrays, and a leaf's primitives
+  // are its range of `order`, so nothing is appended to shared vectors).  The TREE does not depend on the
+  // timing; node numbers do, and the scene images renumber the nodes anyway.
+  std::atomic<int> next_node{1};
+  std::atomic<int> max_depth{0};
+  static constexpr int kParallelMin = 4096;  // primitives
+  static constexpr int kParallelDepth = 4;   // up to 16 concurrent subtrees
   static constexpr int kBins = 16;
   int leaf_max = 4;                      // <= 7 (3 bits in the leaf word)
   double c_trav = 0.0;                   // cost of descending one level, in primitive tests
@@ -76,7 +86,8 @@ struct Builder {
   }
 
   void build(int idx, int lo, int hi, int parent, int depth) {
-    out->depth = std::max(out->depth, depth);
+    for (int d = max_depth.load(std::memory_order_relaxed); depth > d && !max_depth.compare_exchange_weak(d, depth);) {
+    }
     Box b, cb;
     b.reset();
     cb.reset();
@@ -89,11 +100,7 @@ struct Builder {
       }
     }
     const int n = hi - lo;
-    auto make_leaf = [&]() {
-      const int first = (int)out->prim.size();
-      for (int i = lo; i < hi; ++i) out->prim.push_back(order[i]);
-      set_node(idx, b, first, n, parent);
-    };
+    auto make_leaf = [&]() { set_node(idx, b, lo, n, parent); };  // its primitives: order[lo, hi)
     if (n <= 1) {
       make_leaf();
       return;
@@ -174,12 +181,16 @@ struct Builder {
         return cen[(size_t)p * 3 + ax] < cen[(size_t)q * 3 + ax];
       });
     }
-    const int left = (int)(out->link.size() / 4);
-    out->link.resize((size_t)(left + 2) * 4);
-    out->box.resize((size_t)(left + 2) * 6);
+    const int left = next_node.fetch_add(2);
     set_node(idx, b, left, 0, parent);
-    build(left, lo, mid, idx, depth + 1);
-    build(left + 1, mid, hi, idx, depth + 1);
+    if (n >= kParallelMin && depth < kParallelDepth) {
+      auto other = std::async(std::launch::async, [this, left, lo, mid, idx, depth] { build(left, lo, mid, idx, depth + 1); });
+      build(left + 1, mid, hi, idx, depth + 1);
+      other.get();
+    } else {
+      build(left, lo, mid, idx, depth + 1);
+      build(left + 1, mid, hi, idx, depth + 1);
+    }
   }
 };
 
@@ -245,12 +256,17 @@ inline void build_bvh(const std::vector<double> &sph, const std::vector<double> 
   }
   B.order.resize(n);
   for (int i = 0; i < n; ++i) B.order[i] = i;
-  out.box.assign(6, 0.0);
-  out.link.assign(4, 0);
+  // at most 2n - 1 nodes; the arrays are cut to the nodes used afterwards
+  out.box.assign((size_t)std::max(2 * n, 1) * 6, 0.0);
+  out.link.assign((size_t)std::max(2 * n, 1) * 4, 0);
   out.prim.clear();
-  out.prim.reserve(n);
   out.depth = 0;
   if (n > 0) B.build(0, 0, n, -1, 0);
+  const int used = n > 0 ? B.next_node.load() : 1;
+  out.box.resize((size_t)used * 6);
+  out.link.resize((size_t)used * 4);
+  out.prim.assign(B.order.begin(), B.order.end());
+  out.depth = B.max_depth.load();
 }
 
 // ---- scene image for the BVH kernel (layout: rtow_device.h, DevScene::blob) ----------
