@@ -627,8 +627,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       g.r += 1u;
     }
     if constexpr (STAMPS) {  // wave-level count of block evaluations: the first active lane reports
-      if ((do_regen || do_scat) && (int)lane == __ffsll((long long)__ballot(do_regen || do_scat)) - 1)
-        atomicAdd(&P.counters[44], 1ull);
+      if (__ballot(do_regen || do_scat) != 0ull) stamps.blocks += 1;
     }
     real ju = 0, jv = 0, jt = 0, px = 0, py = 0;  // new sample: jitter, shutter time, lens-disk candidate
     V3 rnd = {0, 0, 0}, dirbase = {0, 0, 0};      // bounce: unit-ball candidate, direction before the fuzz term
@@ -667,10 +666,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       rej = dot(rnd, rnd) >= real(1.0);
     }
     // rejection sampling (random-utils.cpp:23-41): every further block carries two candidates
+    uint32_t rej_trips = 0u;  // (diagnostic build only)
     while (rej) {
-      if constexpr (STAMPS) {
-        if ((int)lane == __ffsll((long long)__ballot(true)) - 1) atomicAdd(&P.counters[44], 1ull);
-      }
+      if constexpr (STAMPS) ++rej_trips;
       philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
       g.r += 1u;
       if (do_regen) {
@@ -687,6 +685,16 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         rnd = dot(ca, ca) >= real(1.0) ? cb : ca;
         rej = dot(rnd, rnd) >= real(1.0);
       }
+    }
+    if constexpr (STAMPS) {  // what the wave ran: as many trips as its unluckiest lane needed
+      uint32_t mx = rej_trips, sum = rej_trips;
+      for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t m2 = (uint32_t)__shfl_xor((int)mx, off), s2 = (uint32_t)__shfl_xor((int)sum, off);
+        mx = mx > m2 ? mx : m2;
+        sum += s2;
+      }
+      stamps.blocks += mx;
+      stamps.block_lanes += sum;
     }
     if (do_regen) {
       // src/render.cpp:158-159, src/common-model.cpp:156-167
@@ -742,7 +750,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     }
     const bool tracing = live && !need_sample;  // has a ray to advance in this trip
 
-    stamps.mark(RG_REGEN);
+    stamps.mark(RG_REGEN, __ballot(do_regen || do_scat));
     if constexpr (STAMPS) {
       stamps.trips += 1;
       if (t_empty != 0ull) trips_after_empty += 1;
@@ -765,7 +773,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       if (tracing) best = closest_hit_stream(sc, to_f64(ro), to_f64(rd), (double)rtime);
     }
 
-    stamps.mark(RG_WALK);
+    stamps.mark(RG_WALK, __ballot(tracing));
     bool arrived = tracing;  // the segment's closest hit is known (a stopped GRID / BVH4 walk continues next trip)
     if constexpr (KERNEL == 3) arrived = tracing && !(t_resume > 0.0f);
     if constexpr (KERNEL == 4) arrived = tracing && w_cur == 0x1fffffu;
@@ -816,7 +824,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         ++g.sample;
       }
     }
-    stamps.mark(RG_SHADE);
+    stamps.mark(RG_SHADE, __ballot(arrived));
   }
   if constexpr (STAMPS) {
     if (lane == 0)
@@ -843,6 +851,11 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         }
       }
       for (int r = 0; r < RG_COUNT; ++r) atomicAdd(&P.counters[8 + r], stamps.t[r]);
+      for (int r = 0; r < RG_COUNT; ++r) atomicAdd(&P.counters[23 + r], stamps.lt[r]);
+      atomicAdd(&P.counters[34], stamps.step_lanes);
+      atomicAdd(&P.counters[44], stamps.blocks);
+      atomicAdd(&P.counters[36], stamps.block_lanes);
+      atomicAdd(&P.counters[35], stamps.leaf_lanes);
       atomicAdd(&P.counters[13], stamps.iters);
       atomicAdd(&P.counters[14], stamps.trips);
       atomicAdd(&P.counters[15], stamps.phases);

@@ -230,7 +230,10 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
   uint32_t trips = 0u;                    // wave-uniform
 
   for (;;) {
-    if constexpr (ST) stamps.iters += 1;
+    if constexpr (ST) {
+      stamps.iters += 1;
+      stamps.step_lanes += (unsigned long long)__popcll(__ballot(bvh4_busy(cur, q1)));
+    }
     bvh4_step<FULL>(im, P, ray, tmax32, st, lane_g, cur, sa, q0, q1, nnode);
     const unsigned long long m_walking = __ballot(cur != kRefNone);
     const bool any_walking = m_walking != 0ull;
@@ -240,8 +243,11 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
     const unsigned long long m_pending = __ballot(q0 != kRefNone);
     if ((m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= P.leaf_votes || __ballot(bvh4_busy(cur, q1)) == 0ull)) ||
         !any_walking || suspend) {
-      stamps.mark(RG_WALK);
-      if constexpr (ST) stamps.phases += 1;
+      stamps.mark(RG_WALK, __ballot(active));
+      if constexpr (ST) {
+        stamps.phases += 1;
+        stamps.leaf_lanes += (unsigned long long)__popcll(m_pending);
+      }
       // every lane tests the triangles of the OLDEST leaf it queued
       if (q0 != kRefNone) bvh4_leaf<FULL>(im, sc, q0, o64, d64, best, nprim);
       q0 = q1;
@@ -251,7 +257,7 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
         q0 = kRefNone;
       }
       tmax32 = round_up_f32(best.t);  // rounded up: never below the f64 value
-      stamps.mark(RG_LEAF);
+      stamps.mark(RG_LEAF, m_pending);
       if (suspend) {
         w_cur = cur;  // kRefNone for the lanes that are done
         w_sa = sa;

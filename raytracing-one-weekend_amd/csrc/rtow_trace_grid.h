@@ -123,7 +123,10 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   float t_entry = t0;  // ray parameter at which the lane entered its current cell
   uint32_t trips = 0u;  // wave-uniform
   for (;;) {
-    if constexpr (ST) stamps.iters += 1;
+    if constexpr (ST) {
+      stamps.iters += 1;
+      stamps.step_lanes += (unsigned long long)__popcll(__ballot(walking && q1 == 0u));
+    }
     if (walking && q1 == 0u) {  // (a lane with two cells queued waits for the next leaf phase)
       const uint32_t cw = im.u32(sc.g_off_cells + 4u * (uint32_t)idx);
       ++nnode;
@@ -161,8 +164,11 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
     const unsigned long long m_pending = __ballot(q0 != 0u);
     if ((m_pending != 0ull && ((uint32_t)__popcll(m_pending) >= leaf_votes || __ballot(walking && q1 == 0u) == 0ull)) ||
         !any_walking || suspend) {
-      stamps.mark(RG_WALK);
-      if constexpr (ST) stamps.phases += 1;
+      stamps.mark(RG_WALK, __ballot(active));
+      if constexpr (ST) {
+        stamps.phases += 1;
+        stamps.leaf_lanes += (unsigned long long)__popcll(m_pending);
+      }
       if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
       q0 = q1;
       q1 = 0u;
@@ -171,7 +177,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         q0 = 0u;
       }
       tmax32 = round_up_f32(best.t);
-      stamps.mark(RG_LEAF);
+      stamps.mark(RG_LEAF, m_pending);
       if (suspend) {
         // a lane whose next cell starts beyond the hit it has just found is finished after all
         t_resume = (walking && !(t_entry > tmax32)) ? t_entry : 0.0f;

@@ -10,7 +10,10 @@ template <bool ON>
 struct Stamps {
   unsigned long long t[RG_COUNT] = {0, 0, 0, 0, 0};
   unsigned long long last = 0;
+  unsigned long long lt[RG_COUNT] = {0, 0, 0, 0, 0};    // the same, weighted by the lanes the region worked for
   unsigned long long iters = 0, trips = 0, phases = 0;  // wave-level loop counts
+  unsigned long long blocks = 0, block_lanes = 0;       // Philox block evaluations of the new-ray stage / lanes in its rejection trips
+  unsigned long long step_lanes = 0, leaf_lanes = 0;    // lanes stepping per step-loop iteration / testing per leaf phase
   __device__ __forceinline__ void start() {
     if constexpr (ON) last = now();
   }
@@ -18,6 +21,14 @@ struct Stamps {
     if constexpr (ON) {
       const unsigned long long n = now();
       t[region] += n - last;
+      last = n;
+    }
+  }
+  __device__ __forceinline__ void mark(int region, unsigned long long lanes) {
+    if constexpr (ON) {
+      const unsigned long long n = now();
+      t[region] += n - last;
+      lt[region] += (n - last) * (unsigned long long)__popcll(lanes);
       last = n;
     }
   }

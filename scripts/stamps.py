@@ -26,10 +26,15 @@ for i, n in enumerate(names):
     print(f"{n:12s} {out[8+i]/tot*100:5.1f}%")
 for i, n in enumerate(["large list", "walk set-up", "hit record", "rejection", "sky+unwind"]):
     print(f"{n:12s} {out[29+i]/tot*100:5.1f}%   (split out of walk-steps / shade)")
+print("lanes a region worked for (of 64; entry masks, so an upper bound on what its instructions saw):")
+for i, n in enumerate(names):
+    if out[8 + i]:
+        print(f"{n:12s} {out[23+i]/out[8+i]:5.1f}")
 iters, trips, phases = out[13], out[14], out[15]
+print(f"lanes stepping per step-loop iteration {out[34]/max(iters,1):.1f}; lanes testing per leaf phase {out[35]/max(phases,1):.1f}")
 print(f"wave trips {trips}, step-loop iterations per trip {iters/max(trips,1):.1f}, leaf phases per trip {phases/max(trips,1):.2f}, "
       f"lane-segments per trip {st.segments/max(trips,1):.1f} of 64")
-print(f"Philox block evaluations per trip (wave level, new-ray stage): {out[44]/max(trips,1):.2f}")
+print(f"Philox block evaluations per trip (wave level, new-ray stage): {out[44]/max(trips,1):.2f}; lanes per rejection-loop trip {out[36]/max(out[44]-trips,1):.1f}")
 nw = 4096.0
 print(f"wave end times (ms after first wave start): mean {out[4]/nw/1e5:.3f}  min {out[5]/1e5:.3f}  max {out[6]/1e5:.3f};  queue seen empty (mean over waves) {out[7]/nw/1e5:.3f}")
 
