@@ -971,11 +971,15 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.b4_trips = c->knobs.bvh4_sm ? 0u : 1u;
   {
     const bool b4 = kernel == RTOW_KERNEL_BVH4;
-    const bool b4_full = b4 && scene.b4_lds_limit == scene.blob4_bytes;
+    // every node in LDS (a small mesh, whether or not its triangles are staged too): a walk may stop once 24
+    // lanes are left in it; nodes read from L2 (big mesh): 32 — the longer step hides more of the latency
+    // (suzanne 16 / 20 / 24 / 28 / 32 / 40: 3.65 / 3.82 / 3.88 / 3.86 / 3.79 / 3.63 Gsamples/s; 96.8k mesh
+    // 1.64 / 1.81 / 1.89 / 1.94 / 1.97 / 1.95)
+    const bool b4_nodes_resident = b4 && scene.b4_lds_limit >= scene.b4_off_tri;
     int cap = c->knobs.walk_cap, open = c->knobs.walk_max_open;
     if (cap < 0) {
       cap = b4 ? 4 : 3;
-      open = b4 ? (b4_full ? 24 : 40) : 16;
+      open = b4 ? (b4_nodes_resident ? 24 : 32) : 16;
     }
     // GRID: a resumed lane re-enters one cell BEHIND the cell it stopped at (rtow_trace_grid.h), and up to
     // two cell crossings can share one ray parameter (a ray through a cell corner), so fewer than 3 steps
