@@ -196,7 +196,9 @@ struct Knobs {
   int bvh_leaf = 0;               // RTOW_BVH_LEAF: leaf size cap of the BVH builders (0 = default)
   double bvh_ct = 0.0;            // RTOW_BVH_CT: SAH cost of descending one level
   bool no_leaf_order = false;     // RTOW_NO_LEAF_ORDER
-  double grid_cpp = 1.5;          // RTOW_GRID_CPP: grid cells per primitive
+  double grid_cpp = 1.0;          // RTOW_GRID_CPP: grid cells per primitive (C2 0.5 / 0.75 / 1 / 1.25 / 1.5 / 2 / 2.5:
+                                  // 11.01 / 11.03 / 11.18 / 10.72 / 10.99 / 10.98 / 10.85 Gsamples/s; moving 9.47 / 9.53 / 9.45 /
+                                  // 9.14 / 8.99 / 8.83 / 7.64; 3-D clouds are indifferent, scripts/bench_cloud.py)
   double grid_large = 4.0;        // RTOW_GRID_LARGE: diagonal ratio that makes a primitive "large"
   int grid_max_tris = 8192;       // RTOW_GRID_MAX_TRIS
   unsigned long long partials_cap = 8ull << 30;  // RTOW_PARTIALS_MAX_MB
@@ -223,7 +225,7 @@ struct Knobs {
     bvh_leaf = geti("RTOW_BVH_LEAF", 0);
     bvh_ct = getd("RTOW_BVH_CT", 0.0);
     no_leaf_order = std::getenv("RTOW_NO_LEAF_ORDER") != nullptr;
-    grid_cpp = getd("RTOW_GRID_CPP", 1.5);
+    grid_cpp = getd("RTOW_GRID_CPP", 1.0);
     grid_large = getd("RTOW_GRID_LARGE", 4.0);
     grid_max_tris = geti("RTOW_GRID_MAX_TRIS", 8192);
     if (const char *e = std::getenv("RTOW_PARTIALS_MAX_MB")) partials_cap = (unsigned long long)std::atoll(e) << 20;

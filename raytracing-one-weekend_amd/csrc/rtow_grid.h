@@ -74,11 +74,24 @@ inline void grid_header(const double gmn_in[3], const double gmx_in[3], double s
     ext[k] = std::max(gmx[k] - gmn[k], 1e-9);
   }
   const double target = std::min(std::max(cells_per_prim * (double)n_small, 8.0), 32768.0);
-  const double s = std::cbrt(ext[0] * ext[1] * ext[2] / target);
+  double s = std::cbrt(ext[0] * ext[1] * ext[2] / target);
   const double flat_ratio = grid_flat_ratio();
+  bool flat[3];
+  int thick = 0;
+  double span = 1.0;
+  for (int k = 0; k < 3; ++k) {
+    flat[k] = ext[k] < flat_ratio * s;  // a thin slab: one layer (see grid_flat_ratio())
+    if (!flat[k]) {
+      ++thick;
+      span *= ext[k];
+    }
+  }
+  // the cell count is meant to be `target`: with an axis collapsed to one layer, the cell size follows from the
+  // other axes alone (the cover scene, one layer of spheres: 35 x 1 x 35 cells for a target of 723 otherwise)
+  if (thick > 0 && thick < 3) s = std::pow(span / target, 1.0 / thick);
   for (int k = 0; k < 3; ++k) {
     int nk = (int)std::ceil(ext[k] / s);
-    if (ext[k] < flat_ratio * s) nk = 1;  // a thin slab: one layer (see grid_flat_ratio())
+    if (flat[k]) nk = 1;
     nk = std::min(std::max(nk, 1), 128);
     h.n[k] = nk;
     h.gminf[k] = std::nextafterf((float)gmn[k], -INFINITY);
@@ -170,7 +183,7 @@ inline void write_fat_entry(unsigned char *dst, uint32_t stride, int32_t id, con
 // sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
 inline void build_grid_image(const std::vector<double> &sph, const std::vector<double> &sph_r,
                              const std::vector<double> &mov, const std::vector<double> &tri,
-                             const double cam_origin[3], GridImage &img, double cells_per_prim = 1.5,
+                             const double cam_origin[3], GridImage &img, double cells_per_prim = 1.0,
                              double large_ratio = 4.0, double time0 = 0.0, double time1 = 1.0,
                              const std::vector<int32_t> &prim_mat = {},
                              const std::vector<unsigned char> &mats_bytes = {}) {
