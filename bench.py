@@ -70,7 +70,7 @@ SEED = 1
 # from 4 to 10: C2 (100 spp) 2 -> 8.44, 4 -> 9.38, 5 -> 9.46, 10 -> 9.54, 20 -> 8.96 Gsamples/s;
 # 500 spp on one GPU 4 -> 9.66, 10 -> 10.11, 20 -> 10.19 (scripts/spi_sweep_500.sh).
 SAMPLES_PER_ITEM = int(os.environ.get("RTOW_BENCH_SPI", "10"))
-MESH_SAMPLES_PER_ITEM = int(os.environ.get("RTOW_BENCH_MESH_SPI", "8"))
+MESH_SAMPLES_PER_ITEM = int(os.environ.get("RTOW_BENCH_MESH_SPI", "16"))  # 8 / 16 / 32: 3.99 / 4.02 / 3.99 (C4), 1.966 / 1.974 / 1.964 (C5)
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_VALU_PEAK_TF = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 N_SIMD = 1024

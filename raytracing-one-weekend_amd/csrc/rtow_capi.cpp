@@ -210,7 +210,8 @@ struct Knobs {
   bool bvh4_no_aux = false;       // RTOW_BVH4_NO_AUX: materials / material indices stay in L2 when only the top of the tree is staged
   bool no_bvh4 = false;           // RTOW_NO_BVH4: triangle meshes keep the binary threaded walk
   // Scheduling of the trip kernels (measured on one MI355X; 0 / "off" switches a measure off):
-  int fetch_votes = 4;            // RTOW_FETCH_VOTES: lanes that must need a work item before the fetch block runs
+  int fetch_votes = 0;            // RTOW_FETCH_VOTES: lanes that must need a work item before the fetch block runs
+                                  // (0 = per kernel: 4, BVH4 2 — 2 / 4 / 8: C4 4.01 / 3.99 / 3.89, C5 1.98 / 1.96 / 1.92, C2 10.72 / 10.73 / 10.71)
   int leaf_votes = 0;             // RTOW_LEAF_VOTES: lanes that must hold a queued cell / leaf before a leaf phase
                                   //   (0 = per kernel: GRID 16, BVH4 24)
   int walk_cap = -1, walk_max_open = 0;  // RTOW_WALK_CAP=cap,max_open | off: resumable walk (-1 = per kernel:
@@ -238,7 +239,7 @@ struct Knobs {
     stamps = std::getenv("RTOW_STAMPS") != nullptr;
     no_bvh4 = std::getenv("RTOW_NO_BVH4") != nullptr;
     bvh4_no_aux = std::getenv("RTOW_BVH4_NO_AUX") != nullptr;
-    fetch_votes = std::min(std::max(geti("RTOW_FETCH_VOTES", 4), 1), 64);
+    fetch_votes = std::min(std::max(geti("RTOW_FETCH_VOTES", 0), 0), 64);
     leaf_votes = std::min(std::max(geti("RTOW_LEAF_VOTES", 0), 0), 64);
     bvh4_sm = std::getenv("RTOW_BVH4_SM") != nullptr;
     if (const char *e = std::getenv("RTOW_WALK_CAP")) {
@@ -991,7 +992,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
     P.walk_max_open = (uint32_t)open;
     P.leaf_votes = (uint32_t)(c->knobs.leaf_votes > 0 ? c->knobs.leaf_votes : (b4 ? 24 : 16));
   }
-  P.fetch_votes = (uint32_t)c->knobs.fetch_votes;
+  P.fetch_votes = (uint32_t)(c->knobs.fetch_votes > 0 ? c->knobs.fetch_votes : (kernel == RTOW_KERNEL_BVH4 ? 2 : 4));
   P.sm4_restart = (uint32_t)c->knobs.sm4_votes[0];
   P.sm4_scatter = (uint32_t)c->knobs.sm4_votes[1];
   P.sm4_leaf = (uint32_t)c->knobs.sm4_votes[2];

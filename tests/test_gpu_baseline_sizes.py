@@ -52,8 +52,8 @@ def mesh_obj(tmp_path_factory):
 # config: (W, H, spp, nstreams, bounces, strip height, strips to check)
 C2 = (1200, 800, 100, 10, 50, 8, (0, 30, 47, 99))       # top (sky), horizon, big spheres, bottom rows
 C3 = (1200, 800, 500, 50, 50, 8, (45,))                 # configs[2]'s per-pixel work, one strip
-C4 = (1920, 1080, 256, 32, 20, 8, (4, 67, 130))         # suzanne fills the frame
-C5 = (1920, 1080, 1024, 128, 20, 4, (20, 135, 250))     # 4-row strips: 7.9 M samples each
+C4 = (1920, 1080, 256, 16, 20, 8, (4, 67, 130))          # suzanne fills the frame
+C5 = (1920, 1080, 1024, 64, 20, 4, (20, 135, 250))      # 4-row strips: 7.9 M samples each
 
 
 def strips(ctx, scene, conf, seed=1, fast_on=None):
