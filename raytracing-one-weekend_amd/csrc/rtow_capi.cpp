@@ -194,7 +194,7 @@ void grid_build_release(void *handle);
 // render path touches the environment.
 struct Knobs {
   int bvh_leaf = 0;               // RTOW_BVH_LEAF: leaf size cap of the BVH builders (0 = default)
-  double bvh_ct = 0.0;            // RTOW_BVH_CT: SAH cost of descending one level
+  double bvh_ct = -1.0;           // RTOW_BVH_CT: SAH cost of descending one level (< 0: 0, meshes 1.5)
   bool no_leaf_order = false;     // RTOW_NO_LEAF_ORDER
   double grid_cpp = 1.0;          // RTOW_GRID_CPP: grid cells per primitive (C2 0.5 / 0.75 / 1 / 1.25 / 1.5 / 2 / 2.5:
                                   // 11.01 / 11.03 / 11.18 / 10.72 / 10.99 / 10.98 / 10.85 Gsamples/s; moving 9.47 / 9.53 / 9.45 /
@@ -224,7 +224,7 @@ struct Knobs {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
     auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
     bvh_leaf = geti("RTOW_BVH_LEAF", 0);
-    bvh_ct = getd("RTOW_BVH_CT", 0.0);
+    bvh_ct = getd("RTOW_BVH_CT", -1.0);
     no_leaf_order = std::getenv("RTOW_NO_LEAF_ORDER") != nullptr;
     grid_cpp = getd("RTOW_GRID_CPP", 1.0);
     grid_large = getd("RTOW_GRID_LARGE", 4.0);
@@ -454,6 +454,14 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   // host SAH stops splitting by cost (mostly 1-2 primitives per leaf, cap 4); the radix tree has
   // no cost model, so its leaves are capped at 2 (measured: 1 and 2 equal, 4 is 8-17 % slower)
   int leaf_max = c->builder == RTOW_BUILDER_DEVICE_LBVH ? 2 : 4;
+  // Triangle meshes (the tree the 4-wide image is collapsed from): PAIRS of triangles per leaf — a cost of 1.5
+  // primitive tests per level descended makes the SAH stop at two triangles, the cap keeps it from stopping
+  // earlier.  Against single-triangle leaves (cost 0, what the builder makes of any cap): suzanne 452 -> 261
+  // 4-wide nodes, the whole image now fits LDS with 7 stack entries per lane, 4.06 -> 4.67 Gsamples/s; the
+  // 96.8k-triangle mesh 2.00 -> 2.08.  (Cost 1 / cap 4: 4.45 / 2.01; cap 3: 4.49 / 2.01; cost 3 / cap 2: the same
+  // tree as 1.5 / 2.)  The binary walk over the same tree loses 3.5 % on suzanne (3.39 -> 3.27): it is the fallback.
+  const bool mesh_tree = ns == 0 && nm == 0 && nt > 0 && c->builder != RTOW_BUILDER_DEVICE_LBVH && !c->knobs.no_bvh4;
+  if (mesh_tree) leaf_max = 2;
   if (c->knobs.bvh_leaf > 0) leaf_max = std::min(std::max(c->knobs.bvh_leaf, 1), 7);
   rtow::SceneImage img;
   std::vector<unsigned char> mats_bytes(mats.size() * sizeof(rtow::DevMaterial));
@@ -491,7 +499,7 @@ int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     if (brc) return fail(RTOW_EHIP, "device BVH emit failed (stage %d): %s", brc, hipGetErrorString(hipGetLastError()));
   } else {
     rtow::HostBvh bvh;
-    const double c_trav = c->knobs.bvh_ct;
+    const double c_trav = c->knobs.bvh_ct >= 0.0 ? c->knobs.bvh_ct : (mesh_tree ? 1.5 : 0.0);
     rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
     std::vector<int32_t> prim_order;  // the tree's primitive order before the leaf-order pass renumbers it (for the 4-wide image)
     if (ns == 0 && nm == 0 && !c->knobs.no_bvh4 && leaf_max <= 4) prim_order = bvh.prim;
@@ -990,7 +998,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
     if (cap > 0 && !b4) cap = std::max(cap, 3);
     P.walk_cap = cap > 0 ? (uint32_t)cap : 0xffffffffu;
     P.walk_max_open = (uint32_t)open;
-    P.leaf_votes = (uint32_t)(c->knobs.leaf_votes > 0 ? c->knobs.leaf_votes : (b4 ? 24 : 16));
+    P.leaf_votes = (uint32_t)(c->knobs.leaf_votes > 0 ? c->knobs.leaf_votes : (b4 ? 28 : 16));
   }
   P.fetch_votes = (uint32_t)(c->knobs.fetch_votes > 0 ? c->knobs.fetch_votes : (kernel == RTOW_KERNEL_BVH4 ? 2 : 4));
   P.sm4_restart = (uint32_t)c->knobs.sm4_votes[0];
