@@ -69,7 +69,10 @@ struct Builder {
   std::atomic<int> max_depth{0};
   static constexpr int kParallelMin = 4096;  // primitives
   static constexpr int kParallelDepth = 4;   // up to 16 concurrent subtrees
-  static constexpr int kBins = 16;
+#ifndef RTOW_SAH_BINS
+#define RTOW_SAH_BINS 16
+#endif
+  static constexpr int kBins = RTOW_SAH_BINS;
   int leaf_max = 4;                      // <= 7 (3 bits in the leaf word)
   double c_trav = 0.0;                   // cost of descending one level, in primitive tests
   static constexpr int kSahDepth = 48;   // below this depth fall back to median splits

@@ -870,8 +870,11 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
     if (scene.blob4_bytes + min_k * per_entry <= kLdsLimit) {
       staged = scene.blob4_bytes;
       K = std::min<uint32_t>((kLdsLimit - staged) / per_entry, 32u);
+      if (c->knobs.bvh4_stack_k > 0) K = std::min<uint32_t>(K, (uint32_t)c->knobs.bvh4_stack_k);  // (experiments: fewer)
     } else {
-      K = c->knobs.bvh4_stack_k > 0 ? std::min<uint32_t>((uint32_t)c->knobs.bvh4_stack_k, 32u) : 24u;
+      // (stack entries 6 / 8 / 10 / 12 / 16 / 24 on the 96.8k-triangle mesh: 2.07 / 2.12 / 2.12 / 2.11 / 2.10 / 2.10
+      // Gsamples/s — what the stack does not need holds 128-byte nodes)
+      K = c->knobs.bvh4_stack_k > 0 ? std::min<uint32_t>((uint32_t)c->knobs.bvh4_stack_k, 32u) : 10u;
       // the end of the image goes to LDS as well when it is small: materials + material indices, or the
       // materials alone (shading reads index -> material after every hit: two dependent L2 round trips otherwise)
       const uint32_t aux_max = c->knobs.bvh4_no_aux ? 0u : 16u * 1024u;
