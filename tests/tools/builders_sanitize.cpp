@@ -63,6 +63,13 @@ int main(int argc, char **argv) {
     if (!img4.ok || !rtow::validate_bvh4_image(img4, nt)) return 20 + rep;
     std::printf("mesh %zu triangles: %d BVH2 nodes, %d BVH4 nodes, depth %d, %zu bytes\n", nt, img.n_nodes, img4.n_nodes,
                 img4.depth, img4.blob.size());
+    // the product's tree for meshes: pairs of triangles per leaf (leaf cap 2, level cost 1.5)
+    rtow::HostBvh pairs;
+    rtow::build_bvh(none, none, none, tri, pairs, 2, 1.5, 0.0, 1.0);
+    rtow::Bvh4Image v;
+    rtow::make_bvh4_image(pairs, tri, pmat, mats, cam, v);
+    if (!v.ok || !rtow::validate_bvh4_image(v, nt)) return 60 + rep;
+    std::printf("  pair leaves: %d BVH4 nodes, depth %d, %zu bytes\n", v.n_nodes, v.depth, v.blob.size());
     tri.insert(tri.end(), tri.begin(), tri.begin() + 12 * 50);  // second round: 50 coincident triangles
   }
   {  // one triangle: a single-leaf tree
