@@ -294,7 +294,8 @@ def rooflines(scene, st, kernel_ms, rows, W, workload, precision):
         "pmc_file": pmc.get("pmc_file") if pmc else None,
         "pmc_note": "issue_utilisation = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); lane_activity = "
                     "SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU*64); from separate rocprofv3 --pmc passes of this "
-                    "workload (null: no committed profile matches this workload/kernel)",
+                    "workload (null: no committed profile matches this workload/kernel; the two counters come from "
+                    "different passes, so a saturated kernel can read a few per cent above 1)",
     }
     return roof, valu, walk
 
