@@ -630,3 +630,26 @@ def test_fast_and_f32_builds_are_run_to_run_deterministic(ctx):
             a, _ = ctx.render(scene, cfg)
             b, _ = ctx.render(scene, cfg)
             assert np.array_equal(a, b), (prec, kernel, int((a != b).sum()))
+
+
+def test_build_defaults_that_the_measured_numbers_rest_on():
+    """Guards for two build-time defaults whose effect is large and easy to lose: the mesh tree
+    makes PAIRS of triangles per leaf, which also lets suzanne's whole 4-wide image into LDS with a few stack
+    entries per lane (C4 +15 %), and the grid takes about one cell per small primitive, its cell size refitted over
+    the axes that are not collapsed (C2 +3 %, moving cover +5 %).  The images themselves are covered by the parity
+    tests; this pins their shape."""
+    import struct
+
+    c = rtow.Context(0)
+    c.upload(rtow.HostScene.obj(GOLDEN / "suzanne.obj"))
+    bi = c.build_info()
+    assert 200 <= bi.bvh4_nodes <= 300, bi.bvh4_nodes              # 452 with single-triangle leaves
+    assert bi.bvh4_image_bytes + 6 * 4096 <= 160 * 1024             # whole image + >= 6 stack entries per lane in LDS
+    for moving in (False, True):
+        c.upload(rtow.HostScene.cover(11, 1.5, moving))
+        img = c.debug_image(1)
+        n = struct.unpack_from("<3i", img, 36)
+        assert n[1] == 1 and 20 <= n[0] <= 24 and 20 <= n[2] <= 24, n  # 35 x 1 x 35 before the refit
+        assert struct.unpack_from("<I", img, 60)[0] == (80 if moving else 48)  # fat lists still fit
+        assert len(img) <= 160 * 1024
+    c.close()
