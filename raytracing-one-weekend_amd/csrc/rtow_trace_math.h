@@ -47,20 +47,26 @@ __device__ __forceinline__ Vec3<T> cross(Vec3<T> x, Vec3<T> y) {
 __device__ __forceinline__ V3d to_f64(Vec3<float> v) { return {(double)v.x, (double)v.y, (double)v.z}; }
 __device__ __forceinline__ V3d to_f64(V3d v) { return v; }
 #ifdef RTOW_FAST_MATH
-// fast build: hardware reciprocal-square-root seed (~2^-26) + two Newton steps instead of the
-// correctly rounded sqrt and division (relative error ~1e-16; the strict build keeps IEEE forms)
+// fast build: hardware reciprocal / reciprocal-square-root seed (relative error 5e-8 measured,
+// scripts/experiments/seed_accuracy.hip) + ONE third-order step instead of the correctly rounded division and sqrt:
+// rcp  y (1 + e + e^2), e = 1 - x y              3 fma        max relative error 1.1e-16
+// rsq  y (15/8 - 5/4 z + 3/8 z^2), z = x y^2     2 mul 2 fma 1 mul   3.1e-16   (sqrt: x y in place of y, same count)
+// — two Newton steps (4 and 7 operations) measured 1.9e-16 and 2.4e-16; the strict build keeps the IEEE forms.
 __device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  y = y * (1.5 - 0.5 * x * y * y);
-  y = y * (1.5 - 0.5 * x * y * y);
-  return y;
+  const double y = __builtin_amdgcn_rsq(x);
+  const double z = (x * y) * y;
+  return y * __builtin_fma(z, __builtin_fma(z, 0.375, -1.25), 1.875);
 }
-__device__ __forceinline__ double fast_sqrt(double x) { return x > 0.0 ? x * fast_rsqrt(x) : 0.0; }
+__device__ __forceinline__ double fast_sqrt(double x) {
+  if (!(x > 0.0)) return 0.0;
+  const double y = __builtin_amdgcn_rsq(x);
+  const double s = x * y, z = s * y;
+  return s * __builtin_fma(z, __builtin_fma(z, 0.375, -1.25), 1.875);
+}
 __device__ __forceinline__ double fast_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = y * (2.0 - x * y);
-  y = y * (2.0 - x * y);
-  return y;
+  const double y = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, __builtin_fma(e, e, e), y);
 }
 __device__ __forceinline__ double fast_div(double n, double d) { return n * fast_rcp(d); }
 #else
