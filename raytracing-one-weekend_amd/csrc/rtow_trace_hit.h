@@ -28,25 +28,28 @@ __device__ __forceinline__ void sphere_resolve(T disc, T h, T a, T inv_a, int id
   if (disc >= T(0.0)) {
     T sq = fast_sqrt(disc);
 #if defined(RTOW_FAST_MATH)
-    T root = (-h - sq) * inv_a;
-    const T root2 = (-h + sq) * inv_a;
+    // both roots at once (one reciprocal per ray): root1 <= root2, so a root1 beyond best.t rules out root2 as
+    // well and "the nearer root if it is at or beyond tmin, else the farther one" is the reference's choice
+    // (src/common-model.cpp:76-81) with one comparison less
+    const T root1 = (-h - sq) * inv_a, root2 = (-h + sq) * inv_a;
+    const T root = root1 >= tmin ? root1 : root2;
+    if (root >= tmin && root <= (T)best.t) {
+      best.t = (real)root;
+      best.prim = id;
+    }
 #else
     (void)inv_a;
     T root = (-h - sq) / a;
-#endif
     bool ok = true;
     if (root < tmin || root > (T)best.t) {
-#if defined(RTOW_FAST_MATH)
-      root = root2;
-#else
       root = (-h + sq) / a;
-#endif
       if (root < tmin || root > (T)best.t) ok = false;
     }
     if (ok) {
       best.t = (real)root;
       best.prim = id;
     }
+#endif
   }
 }
 
