@@ -88,7 +88,9 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
         for (uint32_t k = 0; k < count; ++k) {
           const uint32_t e = off.fat + 48u * (first + k);
           const int id = (int)im.u32(e);
-          const double2 p0 = im.d2(e + 16u), p1 = im.d2(e + 32u);
+          double2 p0 = im.d2(e + 16u), p1 = im.d2(e + 32u);
+          // (the record is read together with the id, not after the mailbox test: one LDS round trip per entry)
+          asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p1.x), "+v"(p1.y));
           if (id == last_id) continue;
           last_id = id;
           ++nprim;
@@ -98,7 +100,8 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
         for (uint32_t k = 0; k < count; ++k) {
           const uint32_t e = off.fat + 80u * (first + k);
           const int id = (int)im.u32(e);
-          const double2 p0 = im.d2(e + 16u), p1 = im.d2(e + 32u), p2 = im.d2(e + 48u), p3 = im.d2(e + 64u);
+          double2 p0 = im.d2(e + 16u), p1 = im.d2(e + 32u), p2 = im.d2(e + 48u), p3 = im.d2(e + 64u);
+          asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p1.x), "+v"(p1.y), "+v"(p2.x), "+v"(p2.y), "+v"(p3.x));
           if (id == last_id) continue;
           last_id = id;
           ++nprim;
