@@ -362,6 +362,12 @@ def main():
         a.workload = "moving"
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a))  # nothing above touched the GPU
+    # stdout carries ONE line, the JSON of rank 0: whatever the libraries underneath print there (gloo's "connected
+    # to N peer ranks", an RCCL banner) goes to stderr instead.  The descriptor is swapped, not sys.stdout: those
+    # prints come from C++.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -557,7 +563,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene, label, W, H, DEPTH, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
