@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTOW_ABI_VERSION 4
+#define RTOW_ABI_VERSION 5
 
 /* error codes */
 #define RTOW_OK 0
@@ -39,6 +39,7 @@ extern "C" {
 #define RTOW_ENOSCENE (-4) /* render called before a scene was uploaded    */
 #define RTOW_EEMPTY (-5)   /* scene has no primitives (reference: UB,
                               src/render.cpp:81)                           */
+#define RTOW_ENOMEM (-6)   /* host allocation failed                       */
 
 /* material kinds — Lambertian / Metal / Dielectric (src/common-model.h:124-151) */
 #define RTOW_MAT_LAMBERTIAN 0
@@ -244,6 +245,15 @@ int rtow_profile_collect(rtow_ctx *ctx, double *kernel_ms_sum, int32_t *launches
  * wave end times, [29..33] the finer regions, when the RTOW_STAMPS diagnostic kernel ran). */
 int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out48);
 
+/* Diagnostic only: the LEVELS a render of `cfg` is cut into on this context — pairs (first sample
+ * index, sample count), one work item per pixel and level.  RTOW_F64_STRICT: one level per stream
+ * (spp / nstreams samples, the reference's threads, src/render.cpp:151-166).  Fast builds: a schedule over
+ * the same sample range that does not depend on nstreams — chunks of RTOW_SCHED_CHUNK (16) samples, then
+ * chunks shrinking to single samples at the end of the launch (csrc/rtow_capi.cpp, make_schedule).
+ * Returns the number of levels (writes at most `capacity_pairs` of them).  `ctx` may be NULL: the table
+ * of a new context (pure host arithmetic, usable without a GPU). */
+int rtow_debug_schedule(rtow_ctx *ctx, const rtow_config_t *cfg, uint32_t *out_pairs, int32_t capacity_pairs);
+
 /* Diagnostic only: copies a resident scene image to the host (which: 0 BVH image, 1 grid image,
  * 2 / 3 the same of the RTOW_F32 build).  `out` NULL: size query.  The tests compare host-built
  * and device-built images byte for byte with it. */
@@ -269,6 +279,21 @@ int rtow_render_rgb8(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config
 int rtow_render_multi(int32_t n_devices, const int32_t *device_ids, const rtow_scene_t *scene,
                       const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats, int32_t use_rccl);
 
+/* The same as a persistent handle, for more than one frame: rtow_render_multi pays for its contexts,
+ * streams, buffers, worker threads and — by far the largest item — the RCCL communicator on every call
+ * (it is create + upload + render + destroy).  The handle owns all of them; rtow_multi_upload builds
+ * the scene's acceleration structures once per device (concurrently); rtow_multi_render is then one
+ * trace launch per device, the one ncclGather enqueued behind them on the same streams, one
+ * device-to-host copy into pinned memory and the placement of the rows.  One call in flight per handle.
+ * rtow_multi_build_info reports the first device's build (every device builds the same structures). */
+typedef struct rtow_multi rtow_multi;
+int rtow_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_rccl, rtow_multi **out);
+int rtow_multi_set_builder(rtow_multi *m, int32_t builder);
+int rtow_multi_upload(rtow_multi *m, const rtow_scene_t *scene);
+int rtow_multi_build_info(rtow_multi *m, rtow_build_info_t *out);
+int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats);
+void rtow_multi_destroy(rtow_multi *m);
+
 /* ---- host-side scene construction (no GPU needed) --------------------------
  * C entry points over the C++ mirror of the reference's scene-build API
  * (host/scene.h ≙ src/common-model.h, src/oo-primitives.h, src/render.h):
@@ -284,6 +309,16 @@ typedef struct rtow_host_config_t {
 int rtow_host_scene_cover(const rtow_host_config_t *cfg, rtow_scene_t **out);
 /* foo() (src/main.cpp:85-136): triangles of the first shape of an OBJ file. */
 int rtow_host_scene_obj(const rtow_host_config_t *cfg, const char *obj_path, rtow_scene_t **out);
+/* The same scripts on each of the reference's scene models (it picks one at compile time): OO primitives
+ * (src/oo-primitives.h — what the two entry points above use), variant primitives
+ * (src/variant-primitives.h:84-113, RTWEEKEND_USE_VARIANT_PRIMITIVES) and the World of src/vmodel.h:250-253
+ * (spheres only: the OBJ script has no World form).  Built by the same calls, the models flatten to the
+ * same rtow_scene_t. */
+#define RTOW_MODEL_OO 0
+#define RTOW_MODEL_VARIANT 1
+#define RTOW_MODEL_WORLD 2
+int rtow_host_scene_cover_model(const rtow_host_config_t *cfg, int32_t model, rtow_scene_t **out);
+int rtow_host_scene_obj_model(const rtow_host_config_t *cfg, const char *obj_path, int32_t model, rtow_scene_t **out);
 void rtow_host_scene_free(rtow_scene_t *scene);
 /* Reset the host scene-construction RNG to the reference's default seed. */
 void rtow_host_rng_reset(void);

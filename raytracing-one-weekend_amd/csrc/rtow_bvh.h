@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstring>
 #include <future>
+#include <system_error>
 #include <vector>
 
 namespace rtow {
@@ -67,8 +68,10 @@ struct Builder {
   // timing; node numbers do, and the scene images renumber the nodes anyway.
   std::atomic<int> next_node{1};
   std::atomic<int> max_depth{0};
-  static constexpr int kParallelMin = 4096;  // primitives
+  int parallel_min = 4096;                   // primitives below which a subtree is built by its parent's thread
   static constexpr int kParallelDepth = 4;   // up to 16 concurrent subtrees
+  // tests: 1 = pretend no thread can be started (the std::system_error path below)
+  int fail_thread_start = 0;
 #ifndef RTOW_SAH_BINS
 #define RTOW_SAH_BINS 16
 #endif
@@ -186,10 +189,20 @@ struct Builder {
     }
     const int left = next_node.fetch_add(2);
     set_node(idx, b, left, 0, parent);
-    if (n >= kParallelMin && depth < kParallelDepth) {
-      auto other = std::async(std::launch::async, [this, left, lo, mid, idx, depth] { build(left, lo, mid, idx, depth + 1); });
+    if (n >= parallel_min && depth < kParallelDepth) {
+      // A thread that cannot be started (process limit of the machine: std::async throws std::system_error)
+      // is not an error: its subtree is built here.  The tree is the same either way.
+      std::future<void> other;
+      bool started = false;
+      try {
+        if (fail_thread_start) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+        other = std::async(std::launch::async, [this, left, lo, mid, idx, depth] { build(left, lo, mid, idx, depth + 1); });
+        started = true;
+      } catch (const std::system_error &) {
+      }
+      if (!started) build(left, lo, mid, idx, depth + 1);
       build(left + 1, mid, hi, idx, depth + 1);
-      other.get();
+      if (started) other.get();
     } else {
       build(left, lo, mid, idx, depth + 1);
       build(left + 1, mid, hi, idx, depth + 1);
@@ -212,7 +225,8 @@ inline void pad_box(Box &b) {
 // sph [n][4] cx cy cz r2, sph_r [n]; mov [n][8] c0 delta r2 r; tri [n][12] a e1 e2 n
 inline void build_bvh(const std::vector<double> &sph, const std::vector<double> &sph_r,
                       const std::vector<double> &mov, const std::vector<double> &tri, HostBvh &out,
-                      int leaf_max = 4, double c_trav = 0.0, double time0 = 0.0, double time1 = 1.0) {
+                      int leaf_max = 4, double c_trav = 0.0, double time0 = 0.0, double time1 = 1.0,
+                      int parallel_min = 4096, int fail_thread_start = 0) {
   using namespace bvh_detail;
   const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
   const int n = ns + nm + nt;
@@ -220,6 +234,8 @@ inline void build_bvh(const std::vector<double> &sph, const std::vector<double> 
   B.out = &out;
   B.leaf_max = std::min(std::max(leaf_max, 1), 7);
   B.c_trav = c_trav;
+  B.parallel_min = parallel_min;
+  B.fail_thread_start = fail_thread_start;
   B.pb.resize(n);
   B.cen.resize((size_t)n * 3);
   for (int i = 0; i < ns; ++i) {

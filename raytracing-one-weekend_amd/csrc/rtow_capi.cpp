@@ -38,6 +38,21 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
+// No C++ exception crosses the C ABI (include/rtow.h): the entry points that allocate or start threads run
+// their bodies through this.
+template <class F>
+int guarded(const char *what, F &&f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    return fail(RTOW_ENOMEM, "%s: out of host memory", what);
+  } catch (const std::exception &e) {
+    return fail(RTOW_EINVAL, "%s: %s", what, e.what());
+  } catch (...) {
+    return fail(RTOW_EINVAL, "%s: unknown C++ exception", what);
+  }
+}
+
 }  // namespace
 namespace rtow {
 // for the other translation units of the library (rtow_multi.cpp): same thread-local message
@@ -62,7 +77,7 @@ namespace {
 
 constexpr int kBlock = 256;      // STREAM kernel workgroup
 constexpr int kBvhBlock = 512;   // BVH kernel workgroup (one LDS scene image per workgroup)
-constexpr unsigned kLdsLimit = 160u * 1024u;
+constexpr unsigned kLdsLimit = 160u * 1024u - 64u;  // (64 B: the kernels' static LDS, the workgroup item pool)
 constexpr int kEventRing = 256;
 
 struct DevBuf {
@@ -220,6 +235,10 @@ struct Knobs {
   int sm4_votes[3] = {8, 16, 16};  // RTOW_SM4_VOTES=restart,scatter,leaf: quorum of the state machine's blocks
   int bvh4_stack_k = 0;           // RTOW_BVH4_STACK_K: image staged whole if this many stack entries per lane still fit
                                   //   (default 8), else the entries per lane beside the staged top of the tree (default 24)
+  int sched_chunk = 16;           // RTOW_SCHED_CHUNK: fast builds: samples per work item in the bulk of a launch (0 = no
+                                  //   schedule: one item per stream and pixel, like the strict build)
+  double sched_ratio = 1.3;       // RTOW_SCHED_RATIO: a level of the shrinking end of the schedule is at most 1/ratio of
+                                  //   all the samples that come after it
   void read() {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
     auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
@@ -260,6 +279,8 @@ struct Knobs {
       }
     }
     bvh4_stack_k = std::min(std::max(geti("RTOW_BVH4_STACK_K", 0), 0), 64);
+    sched_chunk = std::min(std::max(geti("RTOW_SCHED_CHUNK", 16), 0), 4096);
+    sched_ratio = std::min(std::max(getd("RTOW_SCHED_RATIO", 1.3), 1.0), 16.0);
   }
 };
 
@@ -289,6 +310,13 @@ struct rtow_ctx {
   // workspace
   DevBuf partials, stack, counters, spill;
   DevBuf out, out8;  // rtow_render / rtow_render_rgb8: device-side output of the host-buffer entry points
+  // level table of the last render ([level][first sample, count], see make_schedule): device copy, pinned
+  // staging buffer, and the key it was built for
+  DevBuf lvl_dev;
+  uint32_t *lvl_pinned = nullptr;
+  size_t lvl_pinned_entries = 0;
+  std::vector<uint32_t> lvl_host;
+  long long lvl_key[4] = {-1, -1, -1, -1};
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
   int occ[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
@@ -305,7 +333,7 @@ int rtow_abi_version(void) { return RTOW_ABI_VERSION; }
 
 const char *rtow_last_error(void) { return g_err.c_str(); }
 
-int rtow_ctx_create(int device_id, rtow_ctx **out) {
+static int impl_ctx_create(int device_id, rtow_ctx **out) {
   if (!out) return fail(RTOW_EINVAL, "rtow_ctx_create: out is NULL");
   *out = nullptr;
   int n = 0;
@@ -328,7 +356,7 @@ int rtow_ctx_create(int device_id, rtow_ctx **out) {
     for (int k = 0; k < 2 && he == hipSuccess; ++k) he = hipEventCreate(&c->ev[i][k]);
   for (int k = 0; k < 2 && he == hipSuccess; ++k) he = hipEventCreate(&c->call_ev[k]);
   if (he == hipSuccess)
-    he = hipHostMalloc((void **)&c->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault);
+    he = hipHostMalloc((void **)&c->h_counters, 48 * sizeof(unsigned long long), hipHostMallocDefault);
   if (he != hipSuccess) {
     rtow_ctx_destroy(c);
     return fail(RTOW_EHIP, "rtow_ctx_create: %s", hipGetErrorString(he));
@@ -343,8 +371,9 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
-                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8})
+                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->lvl_dev})
     b->release();
+  if (c->lvl_pinned) (void)hipHostFree(c->lvl_pinned);
   for (int i = 0; i < kEventRing; ++i)
     for (int k = 0; k < 2; ++k)
       if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
@@ -382,7 +411,7 @@ static int validate_scene(const rtow_scene_t *s) {
   return RTOW_OK;
 }
 
-int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
+static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
   int rc = validate_scene(s);
   if (rc) return rc;
@@ -777,7 +806,67 @@ int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t cap
   return n;
 }
 
-int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
+// The sample schedule of the fast builds: `total` consecutive samples per pixel, cut into levels.  Built from
+// the END of the launch: 1, 1, then each earlier level at most 1/ratio of everything after it, capped at
+// `chunk`; what is left over goes to the front in chunks (a short first chunk takes the remainder).  So the
+// bulk of a launch runs on items of `chunk` samples (few queue fetches and partial sums) and its end on items
+// of one sample: a work item taken late costs no more than the work still queued behind it, and what a wave
+// can be left holding when the queue runs dry is one path, not one item of many samples.
+static void make_schedule(uint32_t first, uint32_t total, uint32_t chunk, double ratio, std::vector<uint32_t> &out) {
+  std::vector<uint32_t> tail;  // in reverse order of execution
+  uint32_t sum = 0;
+  while (sum < total) {
+    uint32_t n = (uint32_t)((double)sum / ratio);
+    n = std::max(n, 1u);
+    n = std::min(n, chunk);
+    if (n >= chunk) break;  // from here on: plain chunks
+    n = std::min(n, total - sum);
+    tail.push_back(n);
+    sum += n;
+  }
+  std::vector<uint32_t> sizes;
+  const uint32_t bulk = total - sum;
+  if (bulk % chunk) sizes.push_back(bulk % chunk);
+  for (uint32_t i = 0; i < bulk / chunk; ++i) sizes.push_back(chunk);
+  for (size_t i = tail.size(); i-- > 0;) sizes.push_back(tail[i]);
+  out.clear();
+  uint32_t at = first;
+  for (uint32_t n : sizes) {
+    out.push_back(at);
+    out.push_back(n);
+    at += n;
+  }
+}
+
+// (diagnostic / tests) the level table a render of `cfg` uses on this context: pairs (first sample, count)
+static int impl_debug_schedule(rtow_ctx *c, const rtow_config_t *cfg, uint32_t *out, int32_t capacity_pairs) {
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  Knobs defaults;  // ctx NULL: the defaults of a new context (pure host arithmetic, usable without a GPU)
+  if (!c) defaults.read();
+  const Knobs &kn = c ? c->knobs : defaults;
+  const uint32_t spt = (uint32_t)(cfg->samples_per_pixel / cfg->nstreams);
+  const uint32_t streams_now = (uint32_t)(cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams);
+  std::vector<uint32_t> t;
+  if (cfg->precision == RTOW_F64_STRICT || kn.sched_chunk == 0 || spt == 0)
+    for (uint32_t k = 0; k < streams_now; ++k) {
+      t.push_back(((uint32_t)cfg->stream_first + k) * spt);
+      t.push_back(spt);
+    }
+  else
+    make_schedule((uint32_t)cfg->stream_first * spt, streams_now * spt, (uint32_t)kn.sched_chunk, kn.sched_ratio, t);
+  const int n = (int)(t.size() / 2);
+  for (int i = 0; i < n && i < capacity_pairs && out; ++i) {
+    out[2 * i] = t[2 * i];
+    out[2 * i + 1] = t[2 * i + 1];
+  }
+  return n;
+}
+
+static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
+                         rtow_stats_t *stats, int lvl_first, int lvl_count, int accumulate);
+
+static int impl_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
                        rtow_stats_t *stats) {
   if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
   int rc = validate_cfg(cfg);
@@ -791,47 +880,98 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   const int spt = cfg->samples_per_pixel / cfg->nstreams;  // src/render.cpp:174
   const unsigned long long npix = (unsigned long long)rows * cfg->image_width;
   const int streams_now = cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams;
-  const unsigned long long n_items = npix * (unsigned long long)streams_now;
-  // Large sample counts: the per-stream partial sums (24 B per pixel and stream) are bounded by
-  // tracing the streams in ranges that accumulate onto d_rgb_sums — bit-identical to one launch
-  // (the reduce kernel adds stream sums in stream order either way).
+  if ((unsigned long long)spt * (unsigned long long)(cfg->stream_first + streams_now) > 0xffffffffULL)
+    return fail(RTOW_EINVAL, "sample index beyond 32 bits");
+  // ---- levels: what one work item per pixel covers (see decode_item in the kernel) ----
+  // strict build: level = stream, the reference's own decomposition (src/render.cpp:169-185), summed in its
+  // order.  Fast builds: a schedule over the same sample range, independent of nstreams (Config::nthreads keeps
+  // its arithmetic meaning — which samples exist — but no longer sets the size of a work item).
+  const bool scheduled = cfg->precision != RTOW_F64_STRICT && c->knobs.sched_chunk > 0 && spt > 0;
   {
-    const unsigned long long cap_bytes = c->knobs.partials_cap;
-    const unsigned long long per_stream = npix * 24ull;
-    unsigned long long max_streams = per_stream ? cap_bytes / per_stream : (unsigned long long)streams_now;
-    if (per_stream && 0xfffffff0ULL / npix < max_streams) max_streams = 0xfffffff0ULL / npix;  // 32-bit item index
-    if (max_streams < 1) max_streams = 1;
-    if ((unsigned long long)streams_now > max_streams && spt > 0 && npix > 0) {
-      rtow_stats_t total;
-      std::memset(&total, 0, sizeof total);
-      const int first0 = cfg->stream_count > 0 ? cfg->stream_first : 0;
-      for (int done = 0; done < streams_now;) {
-        const int now = (int)std::min<unsigned long long>(max_streams, (unsigned long long)(streams_now - done));
-        rtow_config_t part = *cfg;
-        part.stream_first = first0 + done;
-        part.stream_count = now;
-        part.accumulate = (done > 0 || cfg->accumulate) ? 1 : 0;
-        rtow_stats_t st1;
-        rc = rtow_render_device(c, &part, d_rgb_sums, hip_stream, stats ? &st1 : nullptr);
-        if (rc) return rc;
-        if (stats) {
-          total.samples += st1.samples;
-          total.segments += st1.segments;
-          total.prim_tests += st1.prim_tests;
-          total.node_tests += st1.node_tests;
-          total.kernel_ms += st1.kernel_ms;
-          total.total_ms += st1.total_ms;
-          total.local_rows = st1.local_rows;
-          total.kernel_used = st1.kernel_used;
+    const long long key[4] = {scheduled ? c->knobs.sched_chunk : 0, (long long)cfg->stream_first * spt,
+                              (long long)streams_now * spt, scheduled ? -1 : spt};
+    if (std::memcmp(key, c->lvl_key, sizeof key) != 0) {
+      std::vector<uint32_t> &t = c->lvl_host;
+      t.clear();
+      if (scheduled) {
+        make_schedule((uint32_t)cfg->stream_first * (uint32_t)spt, (uint32_t)streams_now * (uint32_t)spt,
+                      (uint32_t)c->knobs.sched_chunk, c->knobs.sched_ratio, t);
+      } else {
+        for (int k = 0; k < streams_now; ++k) {
+          t.push_back((uint32_t)(cfg->stream_first + k) * (uint32_t)spt);
+          t.push_back((uint32_t)spt);
         }
-        done += now;
       }
-      if (stats) *stats = total;
-      return RTOW_OK;
+      if ((rc = c->lvl_dev.ensure(t.size() * sizeof(uint32_t) + 16))) return rc;
+      // the pinned staging copy may still be the source of a copy queued by the previous call
+      HIPCHK(hipStreamSynchronize(st));
+      if (c->lvl_pinned_entries < t.size()) {
+        if (c->lvl_pinned) HIPCHK(hipHostFree(c->lvl_pinned));
+        c->lvl_pinned = nullptr;
+        c->lvl_pinned_entries = 0;
+        const size_t want = t.size() * 2 + 64;
+        HIPCHK(hipHostMalloc((void **)&c->lvl_pinned, want * sizeof(uint32_t), hipHostMallocDefault));
+        c->lvl_pinned_entries = want;
+      }
+      std::memcpy(c->lvl_pinned, t.data(), t.size() * sizeof(uint32_t));
+      HIPCHK(hipMemcpyAsync(c->lvl_dev.p, c->lvl_pinned, t.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+      std::memcpy(c->lvl_key, key, sizeof key);
     }
   }
-  if (n_items > 0xfffffff0ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
+  const int n_levels = (int)(c->lvl_host.size() / 2);
+  // Large sample counts: the per-level partial sums (24 B per pixel and level) are bounded by tracing the
+  // levels in ranges that accumulate onto d_rgb_sums — bit-identical to one launch (the reduce kernel adds
+  // level sums in level order either way).
+  unsigned long long max_levels = (unsigned long long)n_levels;
+  if (npix > 0) {
+    max_levels = c->knobs.partials_cap / (npix * 24ull);
+    if (0xfff00000ULL / npix < max_levels) max_levels = 0xfff00000ULL / npix;  // 32-bit item index
+    if (max_levels < 1) max_levels = 1;
+  }
+  if ((unsigned long long)n_levels <= max_levels || spt == 0 || npix == 0)
+    return render_levels(c, cfg, d_rgb_sums, hip_stream, stats, 0, n_levels, cfg->accumulate);
+  rtow_stats_t total;
+  std::memset(&total, 0, sizeof total);
+  for (int done = 0; done < n_levels;) {
+    const int now = (int)std::min<unsigned long long>(max_levels, (unsigned long long)(n_levels - done));
+    rtow_stats_t st1;
+    rc = render_levels(c, cfg, d_rgb_sums, hip_stream, stats ? &st1 : nullptr, done, now,
+                       (done > 0 || cfg->accumulate) ? 1 : 0);
+    if (rc) return rc;
+    if (stats) {
+      total.samples += st1.samples;
+      total.segments += st1.segments;
+      total.prim_tests += st1.prim_tests;
+      total.node_tests += st1.node_tests;
+      total.kernel_ms += st1.kernel_ms;
+      total.total_ms += st1.total_ms;
+      total.local_rows = st1.local_rows;
+      total.kernel_used = st1.kernel_used;
+    }
+    done += now;
+  }
+  if (stats) *stats = total;
+  return RTOW_OK;
+}
 
+// One launch: levels [lvl_first, lvl_first + lvl_count) of the context's level table.
+static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
+                         rtow_stats_t *stats, int lvl_first, int lvl_count, int accumulate) {
+  int rc;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int rows = rtow_local_rows(cfg);
+  const unsigned long long npix = (unsigned long long)rows * cfg->image_width;
+  const int streams_now = lvl_count;  // levels of this launch
+  const unsigned long long n_items = npix * (unsigned long long)streams_now;
+  unsigned long long samples_per_pixel_now = 0;
+  int spt = 0;  // the longest level of this launch
+  for (int k = 0; k < lvl_count; ++k) {
+    const uint32_t n = c->lvl_host[2 * (size_t)(lvl_first + k) + 1];
+    samples_per_pixel_now += n;
+    spt = std::max(spt, (int)n);
+  }
+  const bool scheduled = c->lvl_key[0] > 0;
+  if (n_items > 0xfff00000ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
   int kernel = cfg->kernel;
   // a handful of primitives is cheaper to stream than to walk
   // AUTO: a handful of primitives is cheaper to stream than to walk; sphere scenes walk the
@@ -903,7 +1043,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   if (npix == 0) return RTOW_OK;
   if (spt == 0) {
     // fewer samples than streams: zero effective samples (src/render.cpp:174), black sums
-    if (!cfg->accumulate) HIPCHK(hipMemsetAsync(d_rgb_sums, 0, (size_t)npix * 3 * sizeof(double), st));
+    if (!accumulate) HIPCHK(hipMemsetAsync(d_rgb_sums, 0, (size_t)npix * 3 * sizeof(double), st));
     if (stats) HIPCHK(hipStreamSynchronize(st));
     return RTOW_OK;
   }
@@ -944,7 +1084,13 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.H = cfg->image_height;
   P.spt = spt;
   P.nstreams = streams_now;
-  P.stream_first = cfg->stream_first;
+  P.level_major = scheduled ? 1u : 0u;
+  P.lvl = (const uint32_t *)c->lvl_dev.p + 2 * (size_t)lvl_first;
+  {
+    // the work a workgroup may still be holding when the queue runs dry: about 1024 samples (one per lane)
+    const uint32_t last = std::max<uint32_t>(c->lvl_host[2 * (size_t)(lvl_first + lvl_count - 1) + 1], 1u);
+    P.wg_batch_floor = std::min<uint32_t>(std::max<uint32_t>(1024u / last, 64u), 1024u);
+  }
   P.max_child_rays = cfg->max_child_rays;
   P.rank = cfg->rank;
   P.nranks = cfg->nranks;
@@ -975,6 +1121,8 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   P.div_tpr_n = th ? (uint32_t)cfg->image_width >> tw : 1u;
   P.div_tpr = make_fastdiv(P.div_tpr_n);
   P.n_tile_rows = th ? (uint32_t)rows >> th : 1u;
+  P.n_tiles = th ? P.n_tile_rows * P.div_tpr_n : 1u;
+  P.div_ntiles = make_fastdiv(P.n_tiles);
   {
     const int eighths = c->knobs.sky_eighths;  // the top eighth of the image is traced last (RTOW_SKY_EIGHTHS: 0..8)
     P.sky_rows = th ? P.n_tile_rows * (uint32_t)eighths / 8u : 0u;
@@ -1031,7 +1179,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
   R.out = (double *)d_rgb_sums;
   R.npix3 = (uint32_t)(npix * 3);
   R.nstreams = streams_now;
-  R.accumulate = cfg->accumulate;
+  R.accumulate = accumulate;
   R.W = (uint32_t)cfg->image_width;
   R.tile_w_log2 = tw;
   R.tile_h_log2 = th;
@@ -1041,9 +1189,12 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
 
   if (stats) {
     HIPCHK(hipEventRecord(c->call_ev[1], st));
-    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters.p, 8 * sizeof(unsigned long long),
+    HIPCHK(hipMemcpyAsync(c->h_counters, c->counters.p, 48 * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (c->h_counters[47] != 0ull)  // the structural bound of the end-of-launch protocol fired (never observed)
+      return fail(RTOW_EHIP, "trace kernel: end-of-launch bound reached, %llu lanes gave up their samples",
+                  c->h_counters[47]);
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, c->call_ev[0], c->call_ev[1]));
     stats->total_ms = ms;
@@ -1051,7 +1202,7 @@ int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, 
       HIPCHK(hipEventElapsedTime(&ms, c->ev[slot][0], c->ev[slot][1]));
       stats->kernel_ms = ms;
     }
-    stats->samples = npix * (unsigned long long)spt * (unsigned long long)streams_now;
+    stats->samples = npix * samples_per_pixel_now;
     stats->segments = c->h_counters[1];
     if (kernel == RTOW_KERNEL_BRUTE) {
       stats->prim_tests = stats->segments * (unsigned long long)c->n_prims;
@@ -1128,7 +1279,7 @@ int rtow_profile_collect(rtow_ctx *c, double *kernel_ms_sum, int32_t *launches) 
   return RTOW_OK;
 }
 
-int rtow_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, double *rgb_sums_host,
+static int impl_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, double *rgb_sums_host,
                 rtow_stats_t *stats) {
   if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
   if (!rgb_sums_host) return fail(RTOW_EINVAL, "rgb_sums_host is NULL");
@@ -1155,7 +1306,7 @@ int rtow_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg
 
 // upload + render + device write_color + copy 8-bit RGB to the host: the whole output path of
 // the reference's render() with 3 bytes per pixel over PCIe instead of 24.
-int rtow_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, unsigned char *rgb8_host,
+static int impl_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, unsigned char *rgb8_host,
                      rtow_stats_t *stats) {
   if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
   if (!rgb8_host) return fail(RTOW_EINVAL, "rgb8_host is NULL");
@@ -1179,4 +1330,27 @@ int rtow_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t
   return rc;
 }
 
+// ---- the guarded entry points (see guarded() above) ----
+int rtow_ctx_create(int device_id, rtow_ctx **out) {
+  return guarded("rtow_ctx_create", [&] { return impl_ctx_create(device_id, out); });
+}
+int rtow_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
+  return guarded("rtow_scene_upload", [&] { return impl_scene_upload(c, s); });
+}
+int rtow_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream, rtow_stats_t *stats) {
+  return guarded("rtow_render_device", [&] { return impl_render_device(c, cfg, d_rgb_sums, hip_stream, stats); });
+}
+int rtow_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, double *rgb_sums_host,
+                rtow_stats_t *stats) {
+  return guarded("rtow_render", [&] { return impl_render(c, scene, cfg, rgb_sums_host, stats); });
+}
+int rtow_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, unsigned char *rgb8_host,
+                     rtow_stats_t *stats) {
+  return guarded("rtow_render_rgb8", [&] { return impl_render_rgb8(c, scene, cfg, rgb8_host, stats); });
+}
+int rtow_debug_schedule(rtow_ctx *c, const rtow_config_t *cfg, uint32_t *out, int32_t capacity_pairs) {
+  return guarded("rtow_debug_schedule", [&] { return impl_debug_schedule(c, cfg, out, capacity_pairs); });
+}
+
 }  // extern "C"
+

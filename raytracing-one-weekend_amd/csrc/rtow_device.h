@@ -80,9 +80,12 @@ struct TraceParams {
   const float *cam32;      // the same 21 values as binary32 (f32 build)
                            // (by value it pinned 42 SGPRs across the whole kernel)
   int32_t W, H;            // full image
-  int32_t spt;             // samples per stream (= spp / nstreams)
-  int32_t nstreams;        // streams traced by THIS launch
-  int32_t stream_first;    // global index of its first stream (sample index = stream * spt + s)
+  int32_t spt;             // the largest sample count of a level of this launch (bounds the tail protocol)
+  int32_t nstreams;        // LEVELS traced by this launch.  A level is a run of consecutive sample indices of every
+                           // pixel, one work item per pixel: a reference "thread" (stream, src/render.cpp:151-166) in
+                           // the strict build, a chunk of the launch's sample range in the fast builds (`lvl`)
+  uint32_t level_major;    // queue order: 0 = tile-major, level-minor (uniform streams); 1 = level-major, the
+                           // levels in table order, so that the launch ends on the shortest items
   int32_t max_child_rays;
   int32_t rank, nranks, tile_rows;
   int32_t local_rows;
@@ -90,14 +93,18 @@ struct TraceParams {
   uint32_t n_items;        // local_rows * W * nstreams
   uint32_t n_lanes;        // grid * block (stride of the path stack)
   FastDiv div_npix, div_w, div_tile;  // item -> (stream, row, column, strip)
-  FastDiv div_ns;                     // tiled order: (item / 64) -> (tile, stream)
+  FastDiv div_ns;                     // tiled order: (item / 64) -> (tile, level)
+  FastDiv div_ntiles;                 // level-major order: (item / 64) -> (level, tile)
+  uint32_t n_tiles;                   // 64-pixel tiles of this rank's rows
+  uint32_t wg_batch_floor; // smallest batch a workgroup takes from the global queue as the queue drains (items)
+  const uint32_t *lvl;     // [nstreams][2]  first sample index, sample count of each level (device memory, scalar loads)
   // pixel order inside this rank's rows: tiles of 2^tile_w_log2 x 2^tile_h_log2 = 64 pixels,
   // tiles row-major (tile_h_log2 == 0 and tile_w_log2 == 0: plain row-major order)
   uint32_t tile_w_log2, tile_h_log2;
   FastDiv div_tpr;         // tiles per row = W >> tile_w_log2
   uint32_t div_tpr_n;      // the divisor itself
   uint32_t n_tile_rows, sky_rows;  // tiled order: tile rows of this rank, and how many of the top ones come last
-  double *partials;        // [nstreams][local_rows*W][3]
+  double *partials;        // [level][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   uint32_t *spill;         // BVH4 kernel: traversal stack entries beyond the LDS part, [entry][n_lanes]
   uint32_t b4_trips;       // BVH4: 1 = the trip-structured kernel (rtow_trace_body.h, default), 0 = the state machine

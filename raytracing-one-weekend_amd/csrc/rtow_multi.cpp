@@ -1,13 +1,23 @@
-// rtow_multi.cpp — rtow_render_multi: one frame over several HIP devices from ONE process.
+// rtow_multi.cpp — one frame over several HIP devices from ONE process: the persistent handle
+// `rtow_multi` and the one-shot rtow_render_multi on top of it.
 //
 // The reference fans its render out over `nthreads` workers and adds their partial images in
 // launch order (src/render.cpp:169-180).  Here a worker is a device: one host thread and one
 // context per device, the image cut into strips of cfg->tile_rows rows dealt round-robin (the
 // partition of include/rtow.h, rank = position in `device_ids`), every device traces its strips
-// into a [max_rows][W][3] f64 buffer, and ONE ncclGather (RCCL over xGMI) brings the buffers to
-// the first device, from where ONE device-to-host copy delivers them; the host then puts every
-// strip row in its place.  Any N gives the one-device image bit for bit (a pixel's value does not
-// depend on who traces it: counter-based RNG, fixed sample order).
+// into a [max_rows][W][3] f64 buffer, and ONE ncclGather (RCCL over xGMI), enqueued on each rank's
+// stream right behind its trace kernel, brings the buffers to the first device, from where ONE
+// device-to-host copy delivers them; the host then puts every strip row in its place.  Any N gives
+// the one-device image bit for bit (a pixel's value does not depend on who traces it:
+// counter-based RNG, fixed sample order).
+//
+// What lives in the handle, created once (rtow_multi_create) and reused by every frame: the
+// contexts (with their scene images and workspaces), one stream per device, the strip buffers,
+// the gather buffer on the first device, the pinned host staging buffer, the RCCL communicator
+// (ncclCommInitAll takes tens of milliseconds — several frames of the cover scene) and the worker
+// threads themselves.  rtow_multi_upload replaces the scene on every device (the acceleration
+// structures are built once per device, concurrently); rtow_multi_render is then launches, one
+// collective and one copy.
 //
 // RCCL is loaded on demand (dlopen of librccl.so) so that librtow.so itself does not depend on it:
 // the one-process-per-GPU form (bench.py, torch.distributed) brings its own RCCL.  With
@@ -16,15 +26,20 @@
 // communicator over duplicate devices cannot exist.
 //
 // Measured: only with ONE device in the communicator (the GPU boxes of this project have one);
-// the N > 1 RCCL path is correct by construction and covered as far as one device allows
-// (tests/test_gpu_parity.py::test_rtweekend_rccl_path_with_one_rank).
+// the N > 1 RCCL path is correct by construction, rehearsed as far as one device allows
+// (tests/test_gpu_parity.py::test_rtweekend_rccl_path_with_one_rank) and checked bit for bit by
+// tests/test_gpu_two_devices.py on the first box that shows two devices.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -65,131 +80,324 @@ struct Rccl {
 };
 
 struct Rank {
+  int device = 0;
   rtow_ctx *ctx = nullptr;
-  void *d_local = nullptr;
   hipStream_t stream = nullptr;
+  void *d_local = nullptr;   // this rank's strips: [max_rows][W][3] f64
+  size_t local_bytes = 0;
+  ncclComm_t comm = nullptr;
   int err = RTOW_OK;
   std::string msg;
   rtow_stats_t stats{};
+  bool hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    err = RTOW_EHIP;
+    msg = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+  }
+  void fail_with_last(int code, const char *what) {
+    err = code;
+    msg = std::string(what) + ": " + rtow_last_error();
+  }
 };
+
+template <class F>
+int guarded(const char *what, F &&f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    return rtow::set_last_error(RTOW_ENOMEM, "%s: out of host memory", what);
+  } catch (const std::exception &e) {
+    return rtow::set_last_error(RTOW_EINVAL, "%s: %s", what, e.what());
+  } catch (...) {
+    return rtow::set_last_error(RTOW_EINVAL, "%s: unknown C++ exception", what);
+  }
+}
 
 }  // namespace
 
-extern "C" int rtow_render_multi(int32_t n_devices, const int32_t *device_ids, const rtow_scene_t *scene,
-                                 const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats,
-                                 int32_t use_rccl) {
-  if (n_devices < 1 || n_devices > 64 || !device_ids) return rtow::set_last_error(RTOW_EINVAL, "rtow_render_multi: 1..64 devices");
-  if (!scene || !cfg || !rgb_sums_host) return rtow::set_last_error(RTOW_EINVAL, "rtow_render_multi: NULL argument");
-  if (cfg->accumulate) return rtow::set_last_error(RTOW_EINVAL, "rtow_render_multi: accumulate is not supported");
-  rtow_config_t probe = *cfg;
-  probe.rank = 0;
-  probe.nranks = n_devices;
-  int max_rows = rtow_local_rows(&probe);  // rank 0 owns the first strip: nobody has more rows
-  if (max_rows < 0) return max_rows;
-  const int W = cfg->image_width, H = cfg->image_height;
-  const size_t count = (size_t)max_rows * (size_t)W * 3;  // doubles per rank in the gather
-  if (count == 0) return RTOW_OK;
-
+// One worker thread per device, alive as long as the handle: run(job) executes job(rank) on every
+// worker and returns when all are done (a frame costs two condition-variable round trips, not N
+// thread creations).
+struct rtow_multi {
+  int n = 0;
+  bool use_rccl = false;
+  bool have_scene = false;
   Rccl rccl;
-  std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
-  if (use_rccl) {
-    std::string why;
-    if (!rccl.load(why)) return rtow::set_last_error(RTOW_ENODEV, "%s", why.c_str());
-    std::vector<int> devs(device_ids, device_ids + n_devices);
-    const ncclResult_t r = rccl.CommInitAll(comms.data(), n_devices, devs.data());
-    if (r != ncclSuccess) {
-      const int rc = rtow::set_last_error(RTOW_EHIP, "ncclCommInitAll over %d devices: %s", n_devices, rccl.GetErrorString(r));
-      dlclose(rccl.lib);
-      return rc;
-    }
-  }
-
-  std::vector<Rank> ranks((size_t)n_devices);
+  std::vector<Rank> ranks;
   void *d_gather = nullptr;  // on the first device: [rank][max_rows][W][3]
-  std::vector<double> staging((size_t)n_devices * count);
+  size_t gather_bytes = 0;
+  double *h_staging = nullptr;  // pinned: what the one device-to-host copy (or the ranks' own copies) fills
+  size_t staging_bytes = 0;
+  // workers
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::function<void(int)> job;
+  unsigned long long generation = 0;
+  int pending = 0;
+  bool quit = false;
 
-  auto work = [&](int r) {
-    Rank &me = ranks[(size_t)r];
-    auto fail = [&](int code, const char *what) {
-      me.err = code;
-      me.msg = std::string(what) + ": " + rtow_last_error();
-    };
-    rtow_config_t mine = *cfg;
-    mine.rank = r;
-    mine.nranks = n_devices;
-    int rc = rtow_ctx_create(device_ids[r], &me.ctx);
-    if (rc) return fail(rc, "rtow_ctx_create");
-    if ((rc = rtow_scene_upload(me.ctx, scene))) return fail(rc, "rtow_scene_upload");
-    auto hip = [&](hipError_t e, const char *what) {
-      if (e == hipSuccess) return true;
-      me.err = RTOW_EHIP;
-      me.msg = std::string(what) + ": " + hipGetErrorString(e);
-      return false;
-    };
-    if (!hip(hipSetDevice(device_ids[r]), "hipSetDevice")) return;
-    if (!hip(hipStreamCreate(&me.stream), "hipStreamCreate")) return;
-    if (!hip(hipMalloc(&me.d_local, count * sizeof(double)), "hipMalloc")) return;
-    if (!hip(hipMemsetAsync(me.d_local, 0, count * sizeof(double), me.stream), "hipMemsetAsync")) return;  // ranks with fewer rows
-    if (r == 0 && use_rccl && !hip(hipMalloc(&d_gather, (size_t)n_devices * count * sizeof(double)), "hipMalloc")) return;
-    if (rtow_local_rows(&mine) > 0) {
-      if ((rc = rtow_render_device(me.ctx, &mine, me.d_local, me.stream, &me.stats))) return fail(rc, "rtow_render_device");
+  void worker(int r) {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::function<void(int)> mine;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_go.wait(lk, [&] { return quit || generation != seen; });
+        if (quit) return;
+        seen = generation;
+        mine = job;
+      }
+      try {
+        mine(r);
+      } catch (const std::exception &e) {
+        ranks[(size_t)r].err = RTOW_EINVAL;
+        ranks[(size_t)r].msg = e.what();
+      } catch (...) {
+        ranks[(size_t)r].err = RTOW_EINVAL;
+        ranks[(size_t)r].msg = "unknown C++ exception";
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (--pending == 0) cv_done.notify_all();
+      }
     }
-    if (!use_rccl) {  // every device delivers its own strips
-      if (!hip(hipMemcpyAsync(staging.data() + (size_t)r * count, me.d_local, count * sizeof(double), hipMemcpyDeviceToHost, me.stream), "hipMemcpyAsync"))
+  }
+  void run(std::function<void(int)> f) {
+    std::unique_lock<std::mutex> lk(mu);
+    job = std::move(f);
+    pending = n;
+    ++generation;
+    cv_go.notify_all();
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  // first error of any rank -> thread-local message of the caller; clears the per-rank state
+  int collect(const char *what) {
+    int rc = RTOW_OK;
+    for (int r = 0; r < n; ++r) {
+      Rank &k = ranks[(size_t)r];
+      if (k.err && rc == RTOW_OK)
+        rc = rtow::set_last_error(k.err, "%s: rank %d (device %d): %s", what, r, k.device, k.msg.c_str());
+      k.err = RTOW_OK;
+      k.msg.clear();
+    }
+    return rc;
+  }
+};
+
+extern "C" {
+
+void rtow_multi_destroy(rtow_multi *m) {
+  if (!m) return;
+  if (!m->threads.empty()) {
+    {
+      std::lock_guard<std::mutex> lk(m->mu);
+      m->quit = true;
+    }
+    m->cv_go.notify_all();
+    for (auto &t : m->threads) t.join();
+  }
+  for (int r = 0; r < (int)m->ranks.size(); ++r) {
+    Rank &k = m->ranks[(size_t)r];
+    (void)hipSetDevice(k.device);
+    if (k.stream) (void)hipStreamSynchronize(k.stream);
+    if (k.d_local) (void)hipFree(k.d_local);
+    if (r == 0 && m->d_gather) (void)hipFree(m->d_gather);
+    if (k.comm) (void)m->rccl.CommDestroy(k.comm);
+    if (k.stream) (void)hipStreamDestroy(k.stream);
+    rtow_ctx_destroy(k.ctx);
+  }
+  if (m->h_staging) (void)hipHostFree(m->h_staging);
+  if (m->rccl.lib) dlclose(m->rccl.lib);
+  delete m;
+}
+
+int rtow_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_rccl, rtow_multi **out) {
+  if (!out) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_create: out is NULL");
+  *out = nullptr;
+  if (n_devices < 1 || n_devices > 64 || !device_ids)
+    return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_create: 1..64 devices");
+  return guarded("rtow_multi_create", [&]() -> int {
+    rtow_multi *m = new rtow_multi();
+    m->n = n_devices;
+    m->use_rccl = use_rccl != 0;
+    m->ranks.resize((size_t)n_devices);
+    for (int r = 0; r < n_devices; ++r) m->ranks[(size_t)r].device = device_ids[r];
+    if (m->use_rccl) {
+      std::string why;
+      if (!m->rccl.load(why)) {
+        const int rc = rtow::set_last_error(RTOW_ENODEV, "%s", why.c_str());
+        rtow_multi_destroy(m);
+        return rc;
+      }
+      std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+      std::vector<int> devs(device_ids, device_ids + n_devices);
+      const ncclResult_t res = m->rccl.CommInitAll(comms.data(), n_devices, devs.data());
+      if (res != ncclSuccess) {
+        const int rc = rtow::set_last_error(RTOW_EHIP, "ncclCommInitAll over %d devices: %s", n_devices,
+                                            m->rccl.GetErrorString(res));
+        rtow_multi_destroy(m);
+        return rc;
+      }
+      for (int r = 0; r < n_devices; ++r) m->ranks[(size_t)r].comm = comms[(size_t)r];
+    }
+    for (int r = 0; r < n_devices; ++r) m->threads.emplace_back([m, r] { m->worker(r); });
+    m->run([m](int r) {
+      Rank &me = m->ranks[(size_t)r];
+      const int rc = rtow_ctx_create(me.device, &me.ctx);
+      if (rc) return me.fail_with_last(rc, "rtow_ctx_create");
+      if (!me.hip(hipSetDevice(me.device), "hipSetDevice")) return;
+      me.hip(hipStreamCreate(&me.stream), "hipStreamCreate");
+    });
+    const int rc = m->collect("rtow_multi_create");
+    if (rc) {
+      const std::string keep = rtow_last_error();
+      rtow_multi_destroy(m);
+      return rtow::set_last_error(rc, "%s", keep.c_str());
+    }
+    *out = m;
+    return RTOW_OK;
+  });
+}
+
+int rtow_multi_set_builder(rtow_multi *m, int32_t builder) {
+  if (!m) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_set_builder: handle is NULL");
+  for (Rank &k : m->ranks) {
+    const int rc = rtow_ctx_set_builder(k.ctx, builder);
+    if (rc) return rc;
+  }
+  return RTOW_OK;
+}
+
+int rtow_multi_upload(rtow_multi *m, const rtow_scene_t *scene) {
+  if (!m || !scene) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_upload: NULL argument");
+  return guarded("rtow_multi_upload", [&]() -> int {
+    m->have_scene = false;
+    m->run([m, scene](int r) {
+      Rank &me = m->ranks[(size_t)r];
+      const int rc = rtow_scene_upload(me.ctx, scene);
+      if (rc) me.fail_with_last(rc, "rtow_scene_upload");
+    });
+    const int rc = m->collect("rtow_multi_upload");
+    m->have_scene = rc == RTOW_OK;
+    return rc;
+  });
+}
+
+int rtow_multi_build_info(rtow_multi *m, rtow_build_info_t *out) {
+  if (!m || !out) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_build_info: NULL argument");
+  return rtow_build_info(m->ranks[0].ctx, out);  // every device builds the same structures
+}
+
+int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats) {
+  if (!m || !cfg || !rgb_sums_host) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_render: NULL argument");
+  if (!m->have_scene) return rtow::set_last_error(RTOW_ENOSCENE, "rtow_multi_render: no scene uploaded");
+  if (cfg->accumulate) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_render: accumulate is not supported");
+  return guarded("rtow_multi_render", [&]() -> int {
+    const int n = m->n;
+    rtow_config_t probe = *cfg;
+    probe.rank = 0;
+    probe.nranks = n;
+    const int max_rows = rtow_local_rows(&probe);  // rank 0 owns the first strip: nobody has more rows
+    if (max_rows < 0) return max_rows;
+    const int W = cfg->image_width;
+    const size_t count = (size_t)max_rows * (size_t)W * 3;  // doubles per rank in the gather
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (count == 0) return RTOW_OK;
+    const size_t bytes = count * sizeof(double);
+    // buffers of the handle, grown on demand (a frame of the same shape allocates nothing)
+    if (m->staging_bytes < (size_t)n * bytes) {
+      if (m->h_staging) (void)hipHostFree(m->h_staging);
+      m->h_staging = nullptr;
+      m->staging_bytes = 0;
+      (void)hipSetDevice(m->ranks[0].device);
+      const hipError_t e = hipHostMalloc((void **)&m->h_staging, (size_t)n * bytes, hipHostMallocPortable);
+      if (e != hipSuccess) return rtow::set_last_error(RTOW_EHIP, "hipHostMalloc of the staging buffer: %s", hipGetErrorString(e));
+      m->staging_bytes = (size_t)n * bytes;
+    }
+    const bool rccl = m->use_rccl;
+    const bool want_stats = stats != nullptr;
+    m->run([m, cfg, n, count, bytes, rccl, want_stats](int r) {
+      Rank &me = m->ranks[(size_t)r];
+      if (!me.hip(hipSetDevice(me.device), "hipSetDevice")) return;
+      if (me.local_bytes < bytes) {
+        if (me.d_local) (void)hipFree(me.d_local);
+        me.d_local = nullptr;
+        me.local_bytes = 0;
+        if (!me.hip(hipMalloc(&me.d_local, bytes), "hipMalloc")) return;
+        me.local_bytes = bytes;
+      }
+      if (r == 0 && rccl && m->gather_bytes < (size_t)n * bytes) {
+        if (m->d_gather) (void)hipFree(m->d_gather);
+        m->d_gather = nullptr;
+        m->gather_bytes = 0;
+        if (!me.hip(hipMalloc(&m->d_gather, (size_t)n * bytes), "hipMalloc")) return;
+        m->gather_bytes = (size_t)n * bytes;
+      }
+      rtow_config_t mine = *cfg;
+      mine.rank = r;
+      mine.nranks = n;
+      const int rows = rtow_local_rows(&mine);
+      std::memset(&me.stats, 0, sizeof me.stats);
+      // ranks with fewer rows than rank 0: the rest of their strip buffer is defined (zero) for the gather
+      if ((size_t)rows * (size_t)cfg->image_width * 3 < count &&
+          !me.hip(hipMemsetAsync(me.d_local, 0, bytes, me.stream), "hipMemsetAsync"))
         return;
-      hip(hipStreamSynchronize(me.stream), "hipStreamSynchronize");
-    }
-  };
-  {
-    std::vector<std::thread> th;
-    for (int r = 0; r < n_devices; ++r) th.emplace_back(work, r);
-    for (auto &t : th) t.join();
-  }
-  int rc = RTOW_OK;
-  for (int r = 0; r < n_devices && rc == RTOW_OK; ++r)
-    if (ranks[(size_t)r].err) rc = rtow::set_last_error(ranks[(size_t)r].err, "rank %d (device %d): %s", r, device_ids[r], ranks[(size_t)r].msg.c_str());
-
-  if (rc == RTOW_OK && use_rccl) {
-    // the one collective: every rank's strip buffer to the first device.  One thread per device calls
-    // ncclGather on its own communicator and stream (the calls of a collective may come from different
-    // threads; each blocks only its own stream).
-    std::vector<ncclResult_t> res((size_t)n_devices, ncclSuccess);
-    std::vector<std::thread> th;
-    for (int r = 0; r < n_devices; ++r)
-      th.emplace_back([&, r] {
-        (void)hipSetDevice(device_ids[r]);
-        res[(size_t)r] = rccl.Gather(ranks[(size_t)r].d_local, r == 0 ? d_gather : nullptr, count, ncclDouble, 0, comms[(size_t)r],
-                                     ranks[(size_t)r].stream);
-        if (res[(size_t)r] == ncclSuccess && hipStreamSynchronize(ranks[(size_t)r].stream) != hipSuccess) res[(size_t)r] = ncclUnhandledCudaError;
+      if (rows > 0) {
+        const int rc = rtow_render_device(me.ctx, &mine, me.d_local, me.stream, want_stats ? &me.stats : nullptr);
+        if (rc) return me.fail_with_last(rc, "rtow_render_device");
+      }
+      if (!rccl) {  // every device delivers its own strips
+        me.hip(hipMemcpyAsync(m->h_staging + (size_t)r * count, me.d_local, bytes, hipMemcpyDeviceToHost, me.stream),
+               "hipMemcpyAsync");
+      }
+    });
+    int rc = m->collect("rtow_multi_render");
+    if (rc == RTOW_OK && rccl) {
+      // the one collective, stream-ordered behind every rank's kernels: each rank's strip buffer to the first
+      // device.  One thread per device calls ncclGather on its own communicator and stream (the calls of a
+      // collective may come from different threads; each enqueues on its own stream).  Rank 0 then enqueues
+      // the one device-to-host copy behind its side of the gather.
+      m->run([m, count](int r) {
+        Rank &me = m->ranks[(size_t)r];
+        if (!me.hip(hipSetDevice(me.device), "hipSetDevice")) return;
+        const ncclResult_t res = m->rccl.Gather(me.d_local, r == 0 ? m->d_gather : nullptr, count, ncclDouble, 0, me.comm, me.stream);
+        if (res != ncclSuccess) {
+          me.err = RTOW_EHIP;
+          me.msg = std::string("ncclGather: ") + m->rccl.GetErrorString(res);
+          return;
+        }
+        if (r == 0)
+          me.hip(hipMemcpyAsync(m->h_staging, m->d_gather, (size_t)m->n * count * sizeof(double), hipMemcpyDeviceToHost, me.stream),
+                 "hipMemcpyAsync of the gathered strips");
       });
-    for (auto &t : th) t.join();
-    for (int r = 0; r < n_devices && rc == RTOW_OK; ++r)
-      if (res[(size_t)r] != ncclSuccess) rc = rtow::set_last_error(RTOW_EHIP, "ncclGather on rank %d: %s", r, rccl.GetErrorString(res[(size_t)r]));
-    if (rc == RTOW_OK) {  // the one device-to-host copy
-      (void)hipSetDevice(device_ids[0]);
-      const hipError_t e = hipMemcpy(staging.data(), d_gather, (size_t)n_devices * count * sizeof(double), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) rc = rtow::set_last_error(RTOW_EHIP, "D2H of the gathered strips: %s", hipGetErrorString(e));
+      rc = m->collect("rtow_multi_render (gather)");
     }
-  }
-
-  if (rc == RTOW_OK) {
+    // wait for every stream (the copies above are the last thing on them)
+    for (int r = 0; r < n; ++r) {
+      Rank &me = m->ranks[(size_t)r];
+      (void)hipSetDevice(me.device);
+      const hipError_t e = hipStreamSynchronize(me.stream);
+      if (e != hipSuccess && rc == RTOW_OK)
+        rc = rtow::set_last_error(RTOW_EHIP, "rank %d (device %d): hipStreamSynchronize: %s", r, me.device, hipGetErrorString(e));
+    }
+    if (rc != RTOW_OK) return rc;
     // strips back to their rows: rank r's i-th local row is global row rows_r[i]
     const size_t row_values = (size_t)W * 3;
     std::vector<int32_t> row_ids((size_t)std::max(max_rows, 1));
-    for (int r = 0; r < n_devices; ++r) {
+    for (int r = 0; r < n; ++r) {
       rtow_config_t mine = *cfg;
       mine.rank = r;
-      mine.nranks = n_devices;
+      mine.nranks = n;
       const int rows = rtow_local_row_list(&mine, row_ids.data(), max_rows);
       for (int i = 0; i < rows; ++i)
-        std::memcpy(rgb_sums_host + (size_t)row_ids[(size_t)i] * row_values, staging.data() + (size_t)r * count + (size_t)i * row_values,
+        std::memcpy(rgb_sums_host + (size_t)row_ids[(size_t)i] * row_values, m->h_staging + (size_t)r * count + (size_t)i * row_values,
                     row_values * sizeof(double));
     }
-    (void)H;
     if (stats) {
-      std::memset(stats, 0, sizeof *stats);
-      for (int r = 0; r < n_devices; ++r) {
-        const rtow_stats_t &s = ranks[(size_t)r].stats;
+      for (int r = 0; r < n; ++r) {
+        const rtow_stats_t &s = m->ranks[(size_t)r].stats;
         stats->samples += s.samples;
         stats->segments += s.segments;
         stats->prim_tests += s.prim_tests;
@@ -200,17 +408,27 @@ extern "C" int rtow_render_multi(int32_t n_devices, const int32_t *device_ids, c
         if (s.kernel_used) stats->kernel_used = s.kernel_used;
       }
     }
-  }
-
-  for (int r = 0; r < n_devices; ++r) {
-    Rank &me = ranks[(size_t)r];
-    (void)hipSetDevice(device_ids[r]);
-    if (me.d_local) (void)hipFree(me.d_local);
-    if (r == 0 && d_gather) (void)hipFree(d_gather);
-    if (me.stream) (void)hipStreamDestroy(me.stream);
-    if (use_rccl && comms[(size_t)r]) (void)rccl.CommDestroy(comms[(size_t)r]);
-    rtow_ctx_destroy(me.ctx);
-  }
-  if (rccl.lib) dlclose(rccl.lib);
-  return rc;
+    return RTOW_OK;
+  });
 }
+
+// The one-shot form: everything above for a single frame (set-up dominates it: use the handle for more than one).
+int rtow_render_multi(int32_t n_devices, const int32_t *device_ids, const rtow_scene_t *scene,
+                      const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats, int32_t use_rccl) {
+  if (n_devices < 1 || n_devices > 64 || !device_ids) return rtow::set_last_error(RTOW_EINVAL, "rtow_render_multi: 1..64 devices");
+  if (!scene || !cfg || !rgb_sums_host) return rtow::set_last_error(RTOW_EINVAL, "rtow_render_multi: NULL argument");
+  if (cfg->accumulate) return rtow::set_last_error(RTOW_EINVAL, "rtow_render_multi: accumulate is not supported");
+  rtow_multi *m = nullptr;
+  int rc = rtow_multi_create(n_devices, device_ids, use_rccl, &m);
+  if (rc == RTOW_OK) rc = rtow_multi_upload(m, scene);
+  if (rc == RTOW_OK) rc = rtow_multi_render(m, cfg, rgb_sums_host, stats);
+  if (rc != RTOW_OK) {
+    const std::string keep = rtow_last_error();
+    rtow_multi_destroy(m);
+    return rtow::set_last_error(rc, "%s", keep.c_str());
+  }
+  rtow_multi_destroy(m);
+  return RTOW_OK;
+}
+
+}  // extern "C"

@@ -83,7 +83,8 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDiv f) {
   return f.shift == 255u ? n : (((n - t) >> 1) + t) >> f.shift;  // shift 255: divisor 1
 }
 
-constexpr uint32_t kItemBatch = 64;  // work items fetched per global atomic (per wave)
+constexpr uint32_t kItemBatch = 64;  // work items a wave takes from its workgroup's pool at a time (one 64-pixel tile)
+constexpr uint32_t kWgBatch = 1024;  // work items a workgroup takes from the global queue per atomic
 
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -103,79 +104,172 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
 }
 
 // ---- work items ------------------------------------------------------------------------------
-// A wave's share of the global item queue: one atomic buys a batch, lanes take items from the
-// wave-local pool [next, end) by ballot rank.  All fields are wave-uniform.
+// Two levels of pools in front of the global queue counter.  A single hot counter word serves ~100
+// atomics/us on this chip, and the queue moves ~1200 items/us on the cover scene — more when the items are
+// single samples (the end of a scheduled launch): one global atomic per wave and fetch throttled every wave of
+// the device to ~40 us per trip during the last tenth of a launch (round-3 diagnostic build; it had been read
+// as an end-of-launch "tail").  So:
+//   * the WORKGROUP pool (LDS word {end:32 | next:32}) is refilled from the global counter by whichever wave finds
+//     it empty and wins the workgroup's lock: up to 1024 items per global atomic;
+//   * a WAVE pool [next, end) (wave-uniform registers) takes up to 64 items — one tile of one level — from the
+//     workgroup pool with ONE LDS atomic, and its lanes take items from it by ballot rank with no traffic.
+// Every queue position is handed out exactly once (the LDS word is only ever advanced by atomics or replaced,
+// under the lock, when it is empty); a lane that gets nothing in a trip — the pool was empty and another wave
+// is refilling it, or it ran dry half-way through the request — asks again in its next trip.
 struct ItemPool {
   uint32_t next = 0, end = 0;
-  unsigned long long seen = 0ull;  // queue head as of this wave's last fetch
+  bool dry = false;  // this wave has seen the end of the queue
 };
+__shared__ unsigned long long rtow_wg_pool;  // {end:32 | next:32}; end == n_items && next >= end: queue exhausted
+__shared__ uint32_t rtow_wg_lock;
+__shared__ unsigned long long rtow_wg_seen;  // the global queue head as of this workgroup's last refill
+
+constexpr unsigned long long kNoItemNow = ~0ull;  // take_items: ask again next trip
+
+__device__ __forceinline__ unsigned long long wave_bcast(unsigned long long v, int src_lane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void item_pools_init() {
+  if (threadIdx.x == 0) {
+    rtow_wg_pool = 0ull;
+    rtow_wg_lock = 0u;
+    rtow_wg_seen = 0ull;
+  }
+}
 
 // Hands one queue position to every lane of `need_mask` (all lanes of the wave call this together).
-// Returns the lane's position, >= kp->n_items when the queue is exhausted.
+// Returns the lane's position; >= kp->n_items when the queue is exhausted; kNoItemNow: none this trip.
 __device__ __forceinline__ unsigned long long take_items(ItemPool &pool, unsigned long long need_mask, unsigned lane,
-                                                         uint32_t n_waves, const RTOW_CONST TraceParams *kp,
+                                                         uint32_t n_wgs, const RTOW_CONST TraceParams *kp,
                                                          unsigned long long *counters) {
-  // Wave-local pool [next, end): one global atomic buys kItemBatch items, which the lanes then take by
-  // ballot rank with no further traffic (a single hot counter word saturates near 90 dequeues/us on this
-  // chip — one atomic per wave trip was the bottleneck).  All of this is wave-uniform except `mine`.
   const uint32_t want = (uint32_t)__popcll(need_mask);
   const uint32_t avail = pool.end - pool.next;
   const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
   unsigned long long mine = (unsigned long long)pool.next + rank;
-  if (want > avail) {
-    // guided self-scheduling: 64 items per atomic while the queue is long, shrinking to
-    // exactly what this wave needs now as it drains (a wave that hoards items at the end
-    // of the queue keeps the whole launch waiting: measured ~4 item durations per launch)
-    const unsigned long long left =
-        (unsigned long long)kp->n_items > pool.seen ? (unsigned long long)kp->n_items - pool.seen : 0ull;
-    uint32_t batch = (uint32_t)(left / ((unsigned long long)n_waves * 4ull));
-    batch = batch > kItemBatch ? kItemBatch : batch;
-    batch = batch < want - avail ? want - avail : batch;
-    const int leader = __ffsll((long long)need_mask) - 1;
-    unsigned long long base = pool.seen;
-    // a wave that has seen the end of the queue stops polling it: at the end of a launch every
-    // wave asks every trip, and the one counter word serves ~100 requests/us (measured: the
-    // last trips of a launch took 34 us instead of 13)
-    if (pool.seen < (unsigned long long)kp->n_items) {
-      if ((int)lane == leader) base = atomicAdd(&counters[0], (unsigned long long)batch);
-      base = __shfl(base, leader);
-    }
-    pool.seen = base + batch;  // how far the queue had advanced when this wave last looked
-    if (rank >= avail) mine = base + (rank - avail);
-    const unsigned long long nn = base + (want - avail), ne = base + batch;
-    const unsigned long long cap = (unsigned long long)kp->n_items;
-    pool.next = (uint32_t)(nn < cap ? nn : cap);
-    pool.end = (uint32_t)(ne < cap ? ne : cap);
-  } else {
+  if (want <= avail) {
     pool.next += want;
+    return mine;
   }
+  const uint32_t n_items = kp->n_items;
+  const uint32_t need = want - avail;
+  const int leader = __ffsll((long long)need_mask) - 1;  // wave-uniform
+  uint32_t nb = 0u, granted = 0u;
+  if (!pool.dry) {
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      unsigned long long w = 0ull;
+      if ((int)lane == leader) w = atomicAdd(&rtow_wg_pool, 0ull);
+      w = wave_bcast(w, leader);
+      const uint32_t wn = (uint32_t)w, we = (uint32_t)(w >> 32);
+      if (wn < we) {
+        // at most a sixteenth of what the workgroup holds, at least what this wave needs now, one tile at most
+        uint32_t ask = (we - wn) >> 4;
+        ask = ask < need ? need : ask;
+        ask = ask > kItemBatch ? kItemBatch : ask;
+        unsigned long long old = 0ull;
+        if ((int)lane == leader) old = atomicAdd(&rtow_wg_pool, (unsigned long long)ask);
+        old = wave_bcast(old, leader);
+        const uint32_t on = (uint32_t)old, oe = (uint32_t)(old >> 32);
+        if (on < oe) {
+          nb = on;
+          granted = oe - on < ask ? oe - on : ask;
+          break;
+        }
+        // (another wave emptied it in between: fall through to the refill)
+      }
+      if (we == n_items) {  // the batch that ended the queue has been handed out
+        pool.dry = true;
+        break;
+      }
+      // refill the workgroup pool: one wave at a time
+      uint32_t won = 0u;
+      if ((int)lane == leader) won = atomicCAS(&rtow_wg_lock, 0u, 1u) == 0u ? 1u : 0u;
+      won = (uint32_t)__builtin_amdgcn_readlane((int)won, leader);
+      if (won == 0u) break;  // a refill is on its way: ask again next trip
+      unsigned long long w2 = 0ull, seen = 0ull;
+      if ((int)lane == leader) {
+        w2 = atomicAdd(&rtow_wg_pool, 0ull);
+        seen = rtow_wg_seen;
+      }
+      w2 = wave_bcast(w2, leader);
+      seen = wave_bcast(seen, leader);
+      if ((uint32_t)w2 >= (uint32_t)(w2 >> 32) && (uint32_t)(w2 >> 32) != n_items) {
+        // guided self-scheduling: the full batch while the queue is long, a share of what is left as it
+        // drains (a workgroup that hoards long items at the end keeps the whole launch waiting), never below
+        // the floor the host derives from the length of the LAST items (single samples: no shrinking at all)
+        const unsigned long long left = (unsigned long long)n_items > seen ? (unsigned long long)n_items - seen : 0ull;
+        uint32_t batch = (uint32_t)(left / ((unsigned long long)n_wgs * 4ull));
+        batch = batch > kWgBatch ? kWgBatch : batch;
+        batch = batch < kp->wg_batch_floor ? kp->wg_batch_floor : batch;
+        unsigned long long g = 0ull;
+        if ((int)lane == leader) g = atomicAdd(&counters[0], (unsigned long long)batch);
+        g = wave_bcast(g, leader);
+        const unsigned long long b0 = g < (unsigned long long)n_items ? g : (unsigned long long)n_items;
+        const unsigned long long b1 = g + batch < (unsigned long long)n_items ? g + batch : (unsigned long long)n_items;
+        if ((int)lane == leader) {
+          rtow_wg_seen = g + batch;
+          (void)atomicExch(&rtow_wg_pool, (b1 << 32) | b0);
+        }
+      }
+      __threadfence_block();
+      if ((int)lane == leader) (void)atomicExch(&rtow_wg_lock, 0u);
+    }
+  }
+  // ranks [0, avail) keep the positions of the old wave pool; [avail, avail + granted) take the new range;
+  // the rest come back next trip — or learn that the queue is exhausted
+  if (rank >= avail) {
+    const uint32_t r2 = rank - avail;
+    mine = r2 < granted ? (unsigned long long)nb + r2 : (pool.dry ? (unsigned long long)n_items : kNoItemNow);
+  }
+  const uint32_t used = need < granted ? need : granted;
+  pool.next = nb + used;
+  pool.end = nb + granted;
   return mine;
 }
 
-// Queue position -> (partial-sum slot, column, global row, first sample index).
-// Queue order.  Tiled mode: tile-major, stream-minor — all streams of a 64-pixel tile are
+// Queue position -> (partial-sum slot, column, global row, sample range).
+// A work item is (level, pixel): the level's run of consecutive samples of one pixel, summed in sample order.
+// Strict build: a level is one reference "thread" (stream): spp / nstreams samples (src/render.cpp:151-166).
+// Fast builds: the levels are a SCHEDULE over the launch's sample range, independent of nstreams — long chunks
+// first, then chunks that shrink geometrically down to single samples (rtow_capi.cpp, make_schedule) — and the
+// queue is level-major, so the launch ends on items of one sample and the end-of-launch tail is one path, not
+// one item.  The sum of a pixel is then the fixed-order sum of its level sums (tolerance build: re-association
+// of the reference's sum, like the contraction it already allows); the image stays a pure function of
+// (scene, config, seed).
+// Queue order.  Uniform levels: tile-major, level-minor — all streams of a 64-pixel tile are
 // adjacent, tiles run top-to-bottom, and the queue is consumed from its far end, so a launch
 // ENDS on the top rows of the image for every stream.  In the reference's scenes that is sky
 // (the top 8 % of the cover image: one-segment paths), so most waves run out of work together:
 // waves finishing > 0.2 ms after they find the queue empty fell from 51 % to 5 % (+1.9 %).
 // (Stream-major order ended only the last stream on the sky; ending on the bottom rows —
-// near ground, short paths — measures the same.)  The partial-sum slot stays [stream][pixel].
+// near ground, short paths — measures the same.)  The partial-sum slot is [level][pixel] in both orders.
 struct ItemPos {
-  uint32_t item, j, gi, sample0;
+  uint32_t item, j, gi, sample0, count;
 };
 __device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp, uint32_t mine, uint32_t npix_local) {
   ItemPos ip;
   const uint32_t qi = kp->n_items - 1u - mine;
   uint32_t k, lp, lr;
-  if (kp->tile_h_log2 == 0u) {  // row-major, stream-major
+  if (kp->tile_h_log2 == 0u) {  // row-major, level-major
     k = fastdiv(qi, FastDiv{kp->div_npix.magic, kp->div_npix.shift});
     lp = qi - k * npix_local;
+    if (kp->level_major != 0u) k = (uint32_t)kp->nstreams - 1u - k;  // table order: the shortest levels last
     lr = fastdiv(lp, FastDiv{kp->div_w.magic, kp->div_w.shift});
     ip.j = lp - lr * (uint32_t)kp->W;
-  } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile of one stream
+  } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile of one level
     const uint32_t g64 = qi >> 6, w = qi & 63u;
-    const uint32_t t = fastdiv(g64, FastDiv{kp->div_ns.magic, kp->div_ns.shift});
-    k = g64 - t * (uint32_t)kp->nstreams;
+    uint32_t t;
+    if (kp->level_major != 0u) {  // every level covers the image once, levels in table order
+      const uint32_t lq = fastdiv(g64, FastDiv{kp->div_ntiles.magic, kp->div_ntiles.shift});
+      t = g64 - lq * kp->n_tiles;
+      k = (uint32_t)kp->nstreams - 1u - lq;
+    } else {  // all levels of a tile adjacent
+      t = fastdiv(g64, FastDiv{kp->div_ns.magic, kp->div_ns.shift});
+      k = g64 - t * (uint32_t)kp->nstreams;
+    }
     const uint32_t trq = fastdiv(t, FastDiv{kp->div_tpr.magic, kp->div_tpr.shift});  // tile row by queue position
     const uint32_t tc = t - trq * (kp->div_tpr_n);
     // Tile rows are consumed from the highest position down.  Positions >= sky_rows hold the
@@ -191,7 +285,20 @@ __device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp,
   const uint32_t q = fastdiv(lr, FastDiv{kp->div_tile.magic, kp->div_tile.shift});
   const uint32_t rr = lr - q * (uint32_t)kp->tile_rows;
   ip.gi = (q * (uint32_t)kp->nranks + (uint32_t)kp->rank) * (uint32_t)kp->tile_rows + rr;
-  ip.sample0 = (k + (uint32_t)kp->stream_first) * (uint32_t)kp->spt;  // first sample index of this stream
+  // The level's sample range, from the table in device memory.  The lanes of a fetch hold consecutive queue
+  // positions, i.e. one level or two: each distinct level costs one scalar load (a loop over the distinct values).
+  ip.sample0 = 0u;
+  ip.count = 0u;
+  const RTOW_CONST uint32_t *lvl = (const RTOW_CONST uint32_t *)kp->lvl;
+  for (bool todo = true; todo;) {
+    const uint32_t ku = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    const uint32_t f = lvl[2u * ku], n = lvl[2u * ku + 1u];
+    if (k == ku) {
+      ip.sample0 = f;
+      ip.count = n;
+      todo = false;
+    }
+  }
   return ip;
 }
 
@@ -288,6 +395,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   [[maybe_unused]] const uint32_t lane_g = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t npix_local = (uint32_t)P.local_rows * (uint32_t)P.W;
 
+  item_pools_init();
   Image<LDS> im;
   im.g = KERNEL == 3 ? sc.gblob : sc.blob;
   [[maybe_unused]] Bvh4Reader<LDS> im4;  // LDS: the whole image is staged; otherwise the top of the tree
@@ -314,6 +422,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     const uint32_t n16 = (KERNEL == 3 ? sc.gblob_bytes : sc.blob_bytes) / 16u;
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
+  } else {
+    __syncthreads();  // the workgroup's item pool
   }
 
   // per-lane state
@@ -351,7 +461,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
   int n_out = 0;           // owner: donated samples not yet added
   uint32_t tail_trips = 0u;
   ItemPool pool;  // wave-uniform: this wave's batch of work items
-  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t n_wgs = gridDim.x;
   Stamps<STAMPS> stamps;
   stamps.start();
   unsigned long long t_empty = 0ull;  // diagnostic: when this wave first saw the queue empty
@@ -393,8 +503,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         dst[2] = acc.z;
         item = 0xffffffffu;
       }
-      const unsigned long long mine = take_items(pool, need_mask, lane, n_waves, kp, P.counters);
-      if (need_item) {
+      const unsigned long long mine = take_items(pool, need_mask, lane, n_wgs, kp, P.counters);
+      if (need_item && mine != kNoItemNow) {
         if (mine >= (unsigned long long)kp->n_items) {
           done = true;
           if constexpr (STAMPS) {
@@ -407,7 +517,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
           gi = ip.gi;
           g.pixel = gi * (uint32_t)kp->W + j;
           g.sample = ip.sample0;
-          s_left = kp->spt;
+          s_left = (int)ip.count;
           acc = {0.0, 0.0, 0.0};
         }
       }
@@ -486,6 +596,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
       // the exit independent of that argument): give up donating, never hang
       // (x64: a stopped-and-resumed walk spreads one segment over several trips)
       if (++tail_trips > 64u * (4096u + 8u * (uint32_t)(P.max_child_rays + 2) * (uint32_t)(P.spt + 1))) {
+        if (!done || holding) atomicAdd(&P.counters[47], 1ull);  // samples dropped: the host turns this into an error
         done = true;
         helping = false;
         holding = false;

@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
   const uint32_t npix_local = (uint32_t)P.local_rows * (uint32_t)P.W;
   const uint32_t kRestartVotes = P.sm4_restart, kScatterVotes = P.sm4_scatter, kLeafVotes = P.sm4_leaf;  // (wave-uniform)
 
+  item_pools_init();
   Bvh4Reader<FULL> im;
   im.g = sc.blob4;
   im.lds_limit = sc.b4_lds_limit;
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
   Rng g = {0, 0, 0};
   uint32_t nseg = 0, nnode = 0, nprim = 0;
   ItemPool pool;
-  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t n_wgs = gridDim.x;
   Stamps<STAMPS> stamps;
   stamps.start();
   if constexpr (STAMPS) {
@@ -128,8 +129,8 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
             dst[1] = acc.y;
             dst[2] = acc.z;
           }
-          const unsigned long long mine = take_items(pool, need_mask, lane, n_waves, kp, P.counters);
-          if (need_item) {
+          const unsigned long long mine = take_items(pool, need_mask, lane, n_wgs, kp, P.counters);
+          if (need_item && mine != kNoItemNow) {
             if (mine >= (unsigned long long)kp->n_items) {
               phase = PH_DEAD;
               item = 0xffffffffu;
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
               gi = ip.gi;
               g.pixel = gi * (uint32_t)kp->W + j;
               g.sample = ip.sample0;
-              s_left = kp->spt;
+              s_left = (int)ip.count;
               acc = {0.0, 0.0, 0.0};
               phase = s_left > 0 ? PH_SAMPLE : PH_ITEM;
             }

@@ -27,28 +27,59 @@ static rt::Config config_from(const rtow_host_config_t *hc) {
   return cfg;
 }
 
-int rtow_host_scene_cover(const rtow_host_config_t *hc, rtow_scene_t **out) {
+int rtow_host_scene_cover_model(const rtow_host_config_t *hc, int32_t model, rtow_scene_t **out) {
   if (!hc || !out) return RTOW_EINVAL;
   try {
-    rt::Scene world = rt::detail::lots_of_balls(config_from(hc));
-    *out = rt::detail::flat_release(rt::detail::flatten(world));
-    return RTOW_OK;
-  } catch (const std::exception &) {
+    switch (model) {
+      case RTOW_MODEL_OO: {
+        rt::Scene world = rt::detail::lots_of_balls(config_from(hc));
+        *out = rt::detail::flat_release(rt::detail::flatten(world));
+        return RTOW_OK;
+      }
+      case RTOW_MODEL_VARIANT: {
+        rt::VariantScene world = rt::detail::lots_of_balls_variant(config_from(hc));
+        *out = rt::detail::flat_release(rt::detail::flatten(world));
+        return RTOW_OK;
+      }
+      case RTOW_MODEL_WORLD: {
+        rt::WorldScene ws = rt::detail::lots_of_balls_world(config_from(hc));
+        *out = rt::detail::flat_release(rt::detail::flatten(ws.world, ws.cam));
+        return RTOW_OK;
+      }
+      default: return RTOW_EINVAL;
+    }
+  } catch (...) {
     return RTOW_EINVAL;
   }
 }
+int rtow_host_scene_cover(const rtow_host_config_t *hc, rtow_scene_t **out) {
+  return rtow_host_scene_cover_model(hc, RTOW_MODEL_OO, out);
+}
 
-int rtow_host_scene_obj(const rtow_host_config_t *hc, const char *obj_path, rtow_scene_t **out) {
+int rtow_host_scene_obj_model(const rtow_host_config_t *hc, const char *obj_path, int32_t model, rtow_scene_t **out) {
   if (!hc || !out || !obj_path) return RTOW_EINVAL;
   try {
     rt::Config cfg = config_from(hc);
     cfg.model = std::string(obj_path);
-    rt::Scene world = rt::detail::foo(cfg);
-    *out = rt::detail::flat_release(rt::detail::flatten(world));
-    return RTOW_OK;
-  } catch (const std::exception &) {
+    switch (model) {
+      case RTOW_MODEL_OO: {
+        rt::Scene world = rt::detail::foo(cfg);
+        *out = rt::detail::flat_release(rt::detail::flatten(world));
+        return RTOW_OK;
+      }
+      case RTOW_MODEL_VARIANT: {
+        rt::VariantScene world = rt::detail::foo_variant(cfg);
+        *out = rt::detail::flat_release(rt::detail::flatten(world));
+        return RTOW_OK;
+      }
+      default: return RTOW_EINVAL;  // (src/vmodel.h's World holds spheres only)
+    }
+  } catch (...) {
     return RTOW_EINVAL;
   }
+}
+int rtow_host_scene_obj(const rtow_host_config_t *hc, const char *obj_path, rtow_scene_t **out) {
+  return rtow_host_scene_obj_model(hc, obj_path, RTOW_MODEL_OO, out);
 }
 
 void rtow_host_scene_free(rtow_scene_t *s) {
@@ -68,14 +99,18 @@ void rtow_host_scene_free(rtow_scene_t *s) {
 int rtow_host_ppm(const double *rgb_sums, int32_t width, int32_t height, int32_t spp_effective,
                   char **out_text, uint64_t *out_len) {
   if (!rgb_sums || !out_text || !out_len || width <= 0 || height <= 0) return RTOW_EINVAL;
-  std::string s = rt::detail::ppm_text(rgb_sums, width, height, spp_effective);
-  char *p = static_cast<char *>(std::malloc(s.size() + 1));
-  if (!p) return RTOW_EINVAL;
-  std::memcpy(p, s.data(), s.size());
-  p[s.size()] = 0;
-  *out_text = p;
-  *out_len = s.size();
-  return RTOW_OK;
+  try {
+    std::string s = rt::detail::ppm_text(rgb_sums, width, height, spp_effective);
+    char *p = static_cast<char *>(std::malloc(s.size() + 1));
+    if (!p) return RTOW_ENOMEM;
+    std::memcpy(p, s.data(), s.size());
+    p[s.size()] = 0;
+    *out_text = p;
+    *out_len = s.size();
+    return RTOW_OK;
+  } catch (...) {
+    return RTOW_ENOMEM;
+  }
 }
 
 void rtow_host_free(void *p) { std::free(p); }

@@ -30,7 +30,10 @@ static void usage(const char *argv0) {
                "  --device INT                HIP device index (default 0)\n"
                "  --seed UINT                 render seed of the counter-based RNG (default 1)\n"
                "  --precision strict|fast|f32 f64 without / with FMA contraction (default fast); f32 = binary32 preview\n"
-               "  --kernel auto|brute|bvh|grid  closest-hit strategy (default auto)\n"
+               "  --kernel auto|brute|bvh|grid|bvh4|reftree  closest-hit strategy (default auto; reftree: the\n"
+               "                              reference's own median-split tree and f64 box test, strict arithmetic)\n"
+               "  --primitives oo|variant|world  scene model the scripts build (the reference picks at compile time;\n"
+               "                              world = src/vmodel.h, spheres only)\n"
                "  --builder host|device       BVH build: host SAH (default) or on the GPU (LBVH)\n"
                "  --p6                        binary P6 output, write_color on the device\n"
                "  --general-obj               with -l: load every shape, not only the first\n"
@@ -109,7 +112,15 @@ int main(int argc, char *argv[]) {
         else if (v == "brute") opt.kernel = 1;
         else if (v == "bvh") opt.kernel = 2;
         else if (v == "grid") opt.kernel = 3;
-        else throw std::runtime_error("--kernel: auto|brute|bvh|grid");
+        else if (v == "bvh4") opt.kernel = 4;
+        else if (v == "reftree") opt.kernel = 5;
+        else throw std::runtime_error("--kernel: auto|brute|bvh|grid|bvh4|reftree");
+      } else if (std::strcmp(a, "--primitives") == 0) {
+        const std::string v = value();
+        if (v == "oo") opt.primitives_model = 0;
+        else if (v == "variant") opt.primitives_model = 1;
+        else if (v == "world") opt.primitives_model = 2;
+        else throw std::runtime_error("--primitives: oo|variant|world");
       } else {
         throw std::runtime_error(std::string("The following argument was not expected: ") + a);
       }
@@ -123,9 +134,23 @@ int main(int argc, char *argv[]) {
     std::cout << cfg;
     return 0;
   }
-  if (cfg.model) {
-    rt::render(rt::detail::foo(cfg), cfg);
-  } else {
-    rt::render(rt::detail::lots_of_balls(cfg), cfg);
+  try {
+    if (cfg.model) {
+      if (opt.primitives_model == 2) throw std::runtime_error("--primitives world: src/vmodel.h's World holds spheres only");
+      if (opt.primitives_model == 1)
+        rt::render(rt::detail::foo_variant(cfg), cfg);
+      else
+        rt::render(rt::detail::foo(cfg), cfg);
+    } else if (opt.primitives_model == 2) {
+      const rt::WorldScene ws = rt::detail::lots_of_balls_world(cfg);
+      rt::render(ws.world, ws.cam, cfg);
+    } else if (opt.primitives_model == 1) {
+      rt::render(rt::detail::lots_of_balls_variant(cfg), cfg);
+    } else {
+      rt::render(rt::detail::lots_of_balls(cfg), cfg);
+    }
+  } catch (const std::exception &e) {  // (the reference lets these escape: terminate)
+    std::cerr << "rtweekend: " << e.what() << "\n";
+    return 1;
   }
 }

@@ -88,6 +88,7 @@ class VariantStore : private std::vector<std::variant<T...>> {
 };
 
 struct World : public VariantStore<Sphere, MovingSphere> {  // src/vmodel.h:250-253
+  using Store = VariantStore<Sphere, MovingSphere>;
   OOStore<Material> boutique;
 };
 
@@ -96,6 +97,7 @@ struct World : public VariantStore<Sphere, MovingSphere> {  // src/vmodel.h:250-
 namespace rtweekend {
 using PrimitiveStore_t = detail::OOStore<detail::Primitive>;
 using MaterialStore_t = detail::OOStore<detail::Material>;
+using VariantPrimitiveStore_t = detail::VariantStore<detail::Sphere, detail::MovingSphere, detail::Triangle>;  // src/variant-primitives.h:104
 using detail::MovingSphere;
 using detail::Sphere;
 using detail::Triangle;

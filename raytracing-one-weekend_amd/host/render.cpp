@@ -9,10 +9,12 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <variant>
 #include <vector>
 
 #include <unistd.h>
@@ -75,9 +77,7 @@ static void put3(double *d, const vec3 &v) {
   d[2] = v.z;
 }
 
-FlatScene *flatten(const Scene &world) {
-  auto *f = new FlatScene();
-  const Camera &c = world.camera();
+static void put_camera(FlatScene *f, const Camera &c) {
   put3(f->s.camera.origin, c.origin());
   put3(f->s.camera.u, c.u());
   put3(f->s.camera.v, c.v());
@@ -88,9 +88,53 @@ FlatScene *flatten(const Scene &world) {
   f->s.camera.lens_radius = c.lens_radius();
   f->s.camera.t0 = c.t0();
   f->s.camera.t1 = c.t1();
+}
 
+// one primitive -> its class's record array (insertion order kept in prim_kind / prim_index)
+static void put_primitive(FlatScene *f, const Sphere &s, int32_t mi) {
+  f->pk.push_back(RTOW_PRIM_SPHERE);
+  f->pi.push_back((int32_t)f->sm.size());
+  f->sg.insert(f->sg.end(), {s.center().x, s.center().y, s.center().z, s.radius()});
+  f->sm.push_back(mi);
+}
+static void put_primitive(FlatScene *f, const MovingSphere &s, int32_t mi) {
+  f->pk.push_back(RTOW_PRIM_MOVING_SPHERE);
+  f->pi.push_back((int32_t)f->mm.size());
+  f->mg.insert(f->mg.end(), {s.center().x, s.center().y, s.center().z, s.center1().x, s.center1().y, s.center1().z,
+                             s.radius(), 0.0});
+  f->mm.push_back(mi);
+}
+static void put_primitive(FlatScene *f, const Triangle &t, int32_t mi) {
+  f->pk.push_back(RTOW_PRIM_TRIANGLE);
+  f->pi.push_back((int32_t)f->tm.size());
+  f->tg.insert(f->tg.end(), {t.a().x, t.a().y, t.a().z, t.b().x, t.b().y, t.b().z, t.c().x, t.c().y, t.c().z});
+  f->tm.push_back(mi);
+}
+// the two store flavours: OO (unique_ptr<Primitive>, dispatch on kind()) and variant (std::visit,
+// src/variant-primitives.h:107-113)
+static const Primitive &as_primitive(const std::unique_ptr<Primitive> &p) { return *p; }
+template <class... T>
+static const Primitive &as_primitive(const std::variant<T...> &v) {
+  return std::visit([](const auto &x) -> const Primitive & { return x; }, v);
+}
+static void put_any(FlatScene *f, const std::unique_ptr<Primitive> &p, int32_t mi) {
+  switch (p->kind()) {
+    case Primitive::Kind::sphere: put_primitive(f, static_cast<const Sphere &>(*p), mi); break;
+    case Primitive::Kind::moving_sphere: put_primitive(f, static_cast<const MovingSphere &>(*p), mi); break;
+    case Primitive::Kind::triangle: put_primitive(f, static_cast<const Triangle &>(*p), mi); break;
+  }
+}
+template <class... T>
+static void put_any(FlatScene *f, const std::variant<T...> &v, int32_t mi) {
+  std::visit([&](const auto &x) { put_primitive(f, x, mi); }, v);
+}
+
+template <class PrimStore>
+static FlatScene *flatten_parts(const Camera &cam, const PrimStore &prims, const MaterialStore_t &boutique) {
+  auto f = std::make_unique<FlatScene>();
+  put_camera(f.get(), cam);
   std::unordered_map<const Material *, int32_t> mat_index;
-  for (auto it = world.boutique().cbegin(); it != world.boutique().cend(); ++it) {
+  for (auto it = boutique.cbegin(); it != boutique.cend(); ++it) {
     const Material *m = it->get();
     rtow_material_t r;
     std::memset(&r, 0, sizeof r);
@@ -111,43 +155,22 @@ FlatScene *flatten(const Scene &world) {
     mat_index[m] = (int32_t)f->mats.size();
     f->mats.push_back(r);
   }
-  for (auto it = world.primitives().cbegin(); it != world.primitives().cend(); ++it) {
-    const Primitive *p = it->get();
-    auto found = mat_index.find(&p->material());
-    if (found == mat_index.end()) {
-      delete f;
+  for (auto it = prims.cbegin(); it != prims.cend(); ++it) {
+    auto found = mat_index.find(&as_primitive(*it).material());
+    if (found == mat_index.end())
       throw std::runtime_error("primitive refers to a material that is not in the scene's boutique");
-    }
-    const int32_t mi = found->second;
-    f->pk.push_back(static_cast<int32_t>(p->kind()));
-    switch (p->kind()) {
-      case Primitive::Kind::sphere: {
-        auto *s = static_cast<const Sphere *>(p);
-        f->pi.push_back((int32_t)f->sm.size());
-        f->sg.insert(f->sg.end(), {s->center().x, s->center().y, s->center().z, s->radius()});
-        f->sm.push_back(mi);
-        break;
-      }
-      case Primitive::Kind::moving_sphere: {
-        auto *s = static_cast<const MovingSphere *>(p);
-        f->pi.push_back((int32_t)f->mm.size());
-        f->mg.insert(f->mg.end(), {s->center().x, s->center().y, s->center().z, s->center1().x,
-                                   s->center1().y, s->center1().z, s->radius(), 0.0});
-        f->mm.push_back(mi);
-        break;
-      }
-      case Primitive::Kind::triangle: {
-        auto *t = static_cast<const Triangle *>(p);
-        f->pi.push_back((int32_t)f->tm.size());
-        f->tg.insert(f->tg.end(), {t->a().x, t->a().y, t->a().z, t->b().x, t->b().y, t->b().z,
-                                   t->c().x, t->c().y, t->c().z});
-        f->tm.push_back(mi);
-        break;
-      }
-    }
+    put_any(f.get(), *it, found->second);
   }
   f->bind();
-  return f;
+  return f.release();
+}
+
+FlatScene *flatten(const Scene &world) { return flatten_parts(world.camera(), world.primitives(), world.boutique()); }
+FlatScene *flatten(const VariantScene &world) {
+  return flatten_parts(world.camera(), world.primitives(), world.boutique());
+}
+FlatScene *flatten(const World &world, const Camera &camera) {
+  return flatten_parts(camera, static_cast<const World::Store &>(world), world.boutique);
 }
 
 const rtow_scene_t *flat_view(const FlatScene *f) { return &f->s; }
@@ -198,7 +221,13 @@ std::string ppm_text(const double *rgb_sums, int width, int height, int spp_effe
   return s;
 }
 
-void render(const Scene &world, const Config &cfg) {
+static void render_flat(FlatScene *flat, const Config &cfg);
+void render(const Scene &world, const Config &cfg) { render_flat(flatten(world), cfg); }
+void render(const VariantScene &world, const Config &cfg) { render_flat(flatten(world), cfg); }
+void render(const World &world, const Camera &camera, const Config &cfg) { render_flat(flatten(world, camera), cfg); }
+
+// (takes ownership of `flat`)
+static void render_flat(FlatScene *flat, const Config &cfg) {
   int image_height = static_cast<int>(cfg.image_width / cfg.aspect_ratio);  // src/render.cpp:137
   namespace khr = std::chrono;
   const DeviceOptions &opt = device_options();
@@ -206,7 +235,6 @@ void render(const Scene &world, const Config &cfg) {
             << opt.device << (opt.gpus > 1 ? " (+" + std::to_string(opt.gpus - 1) + " more)" : std::string()) << "\n";
   khr::time_point start{khr::high_resolution_clock::now()};
 
-  FlatScene *flat = flatten(world);
   rtow_config_t rc;
   std::memset(&rc, 0, sizeof rc);
   rc.image_width = cfg.image_width;
@@ -238,22 +266,31 @@ void render(const Scene &world, const Config &cfg) {
     for (int r = 0; r < ngpus; ++r) devs[(size_t)r] = opt.gpus_same_device ? opt.device : opt.device + r;
     std::vector<double> sums(nvalues);
     const int use_rccl = opt.gpus_same_device && ngpus > 1 ? 0 : 1;
-    if (opt.builder >= 0) setenv("RTOW_BUILDER", opt.builder == RTOW_BUILDER_DEVICE_LBVH ? "device" : "host", 1);
     // RCCL prints a version banner on stdout when it initialises; stdout is the PPM (src/render.cpp:182-186),
-    // so the banner is sent to stderr for the duration of the call
+    // so the banner is sent to stderr while the communicator is created (rtow_multi_create; nothing else of
+    // this process writes to stdout in the meantime)
     std::cout.flush();
     std::fflush(stdout);
     const int saved_stdout = dup(1);
     if (saved_stdout >= 0) (void)dup2(2, 1);
-    const int err = nvalues ? rtow_render_multi(ngpus, devs.data(), flat_view(flat), &rc, sums.data(), &st, use_rccl) : RTOW_OK;
+    rtow_multi *multi = nullptr;
+    int err = rtow_multi_create(ngpus, devs.data(), use_rccl, &multi);
     std::fflush(stdout);
     if (saved_stdout >= 0) {
       (void)dup2(saved_stdout, 1);
       close(saved_stdout);
     }
+    std::string msg = err == RTOW_OK ? std::string() : std::string(rtow_last_error());
+    if (err == RTOW_OK && opt.builder >= 0 && (err = rtow_multi_set_builder(multi, opt.builder))) msg = rtow_last_error();
+    if (err == RTOW_OK && nvalues) {
+      if ((err = rtow_multi_upload(multi, flat_view(flat))) || (err = rtow_multi_render(multi, &rc, sums.data(), &st)))
+        msg = rtow_last_error();
+      else
+        (void)rtow_multi_build_info(multi, &bi);
+    }
+    rtow_multi_destroy(multi);
     flat_free(flat);
-    if (err != RTOW_OK)
-      throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + rtow_last_error());
+    if (err != RTOW_OK) throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + msg);
     if (opt.binary_ppm) {  // write_color on the host: the same correctly rounded operations as the device epilogue
       for (size_t q = 0; q < nvalues; ++q) {
         double c = std::sqrt(sums[q] / static_cast<double>(spp_eff_all));

@@ -43,27 +43,54 @@ struct DeviceOptions {
   int gpus = 1;
   bool gpus_same_device = false;
   bool rccl = false;
+  // which of the reference's scene models the scene scripts build (the reference picks at compile time):
+  // 0 OO primitives (default, src/oo-primitives.h), 1 variant primitives (src/variant-primitives.h),
+  // 2 the World of src/vmodel.h (spheres only)
+  int primitives_model = 0;
 };
 DeviceOptions &device_options();
 
-class Scene {
-  mutable PrimitiveStore_t primitives_;
+// Scene (src/render.h:22-33) over either of the reference's two interchangeable primitive stores:
+// the OO store (src/oo-primitives.h:102) or the variant store (src/variant-primitives.h:104,
+// RTWEEKEND_USE_VARIANT_PRIMITIVES in the reference's build).
+template <class PrimStore>
+class BasicScene {
+  mutable PrimStore primitives_;
   MaterialStore_t boutique_;
   Camera cam_;
 
  public:
   template <typename T>
-  explicit Scene(T &&camera) : cam_{std::forward<T>(camera)} {}
+  explicit BasicScene(T &&camera) : cam_{std::forward<T>(camera)} {}
   auto &camera() const { return cam_; }
   auto &primitives() { return primitives_; }
   const auto &primitives() const { return primitives_; }
   auto &boutique() { return boutique_; }
   const auto &boutique() const { return boutique_; }
 };
+using Scene = BasicScene<PrimitiveStore_t>;
+using VariantScene = BasicScene<VariantPrimitiveStore_t>;
 
-// Flattened copy of a Scene (owns the arrays an rtow_scene_t points into).
+// The legacy model of src/vmodel.h:250-253 — a World of spheres that owns its materials — has no camera of
+// its own; this pairs one with it so that the scene scripts and flatten() treat all three models alike.
+struct WorldScene {
+  World world;
+  Camera cam;
+  template <typename T>
+  explicit WorldScene(T &&camera) : cam{std::forward<T>(camera)} {}
+  auto &camera() const { return cam; }
+  auto &primitives() { return static_cast<World::Store &>(world); }
+  const auto &primitives() const { return static_cast<const World::Store &>(world); }
+  auto &boutique() { return world.boutique; }
+  const auto &boutique() const { return world.boutique; }
+};
+
+// Flattened copy of a scene (owns the arrays an rtow_scene_t points into).  The three models flatten to
+// the same rtow_scene_t when they were built by the same calls (tests/test_host_api.py).
 struct FlatScene;
 FlatScene *flatten(const Scene &world);
+FlatScene *flatten(const VariantScene &world);
+FlatScene *flatten(const World &world, const Camera &camera);
 const rtow_scene_t *flat_view(const FlatScene *f);
 rtow_scene_t *flat_release(FlatScene *f);  // heap rtow_scene_t owning malloc'ed arrays
 void flat_free(FlatScene *f);
@@ -72,12 +99,17 @@ void flat_free(FlatScene *f);
 // diagnostics to std::cerr (src/render.cpp:135-191).  Throws std::runtime_error
 // if the device path fails — there is no CPU fallback.
 void render(const Scene &world, const Config &cfg);
+void render(const VariantScene &world, const Config &cfg);                 // the reference's Scene over variant primitives
+void render(const World &world, const Camera &camera, const Config &cfg);  // src/vmodel.h's World
 
 std::ostream &operator<<(std::ostream &o, const Config &c);
 
-// The two scene scripts of the reference's main.cpp.
+// The two scene scripts of the reference's main.cpp, on each of the scene models.
 Scene lots_of_balls(const Config &cfg);  // src/main.cpp:23-83
 Scene foo(const Config &cfg);            // src/main.cpp:85-136
+VariantScene lots_of_balls_variant(const Config &cfg);
+VariantScene foo_variant(const Config &cfg);
+WorldScene lots_of_balls_world(const Config &cfg);
 
 }  // namespace rtweekend::detail
 
@@ -87,4 +119,6 @@ using detail::DeviceOptions;
 using detail::device_options;
 using detail::render;
 using detail::Scene;
+using detail::VariantScene;
+using detail::WorldScene;
 }  // namespace rtweekend

@@ -17,16 +17,18 @@ namespace rt = rtweekend;
 
 namespace rtweekend::detail {
 
-// src/main.cpp:23-83
-Scene lots_of_balls(const Config &cfg) {
+// src/main.cpp:23-83, on any of the scene models (render.h): the same calls in the same order, so the three
+// flatten to the same records
+template <class SceneT>
+static SceneT lots_of_balls_on(const Config &cfg) {
   rt::Camera cam{rt::point(13, 2, 3), rt::point(0, 0, 0), rt::vec3(0, 1, 0), 20.0,
                  cfg.aspect_ratio,    0.1,               10.0,              0,
                  1};
-  rt::Scene world{cam};
+  SceneT world{cam};
   auto &boutique = world.boutique();
 
-  auto &ground_material = boutique.add<rt::Lambertian>(rt::color{0.5, 0.5, 0.5});
-  world.primitives().add<rt::Sphere>(rt::point{0, -1000, 0}, 1000.0, ground_material);
+  auto &ground_material = boutique.template add<rt::Lambertian>(rt::color{0.5, 0.5, 0.5});
+  world.primitives().template add<rt::Sphere>(rt::point{0, -1000, 0}, 1000.0, ground_material);
 
   const int nsqrt = cfg.number_of_balls_sqrt;
   for (int a = -nsqrt; a < nsqrt; a++) {
@@ -41,34 +43,37 @@ Scene lots_of_balls(const Config &cfg) {
         if (choose_mat < 0.8) {  // diffuse
           const rt::color a1 = rt::random_vec3();
           const rt::color a2 = rt::random_vec3();
-          auto &mat = boutique.add<rt::Lambertian>(a1 * a2);
+          auto &mat = boutique.template add<rt::Lambertian>(a1 * a2);
           if (cfg.moving_spheres) {
             const rt::point center2 = center + rt::point(0, rt::random_double(0, .5), 0);
-            world.primitives().add<rt::MovingSphere>(center, center2, 0.2, mat);
+            world.primitives().template add<rt::MovingSphere>(center, center2, 0.2, mat);
           } else {
-            world.primitives().add<rt::Sphere>(center, 0.2, mat);
+            world.primitives().template add<rt::Sphere>(center, 0.2, mat);
           }
         } else if (choose_mat < 0.95) {  // metal
           const rt::color albedo = rt::random_vec3(0.5, 1);
           const double fuzz = rt::random_double(0, 0.5);
-          auto &mat = boutique.add<rt::Metal>(albedo, fuzz);
-          world.primitives().add<rt::Sphere>(center, 0.2, mat);
+          auto &mat = boutique.template add<rt::Metal>(albedo, fuzz);
+          world.primitives().template add<rt::Sphere>(center, 0.2, mat);
         } else {  // glass
-          auto &mat = boutique.add<rt::Dielectric>(1.5);
-          world.primitives().add<rt::Sphere>(center, 0.2, mat);
+          auto &mat = boutique.template add<rt::Dielectric>(1.5);
+          world.primitives().template add<rt::Sphere>(center, 0.2, mat);
         }
       }
     }
   }
 
-  auto &glass = boutique.add<rt::Dielectric>(1.5);
-  auto &reddish = boutique.add<rt::Lambertian>(rt::color{0.4, 0.2, 0.1});
-  auto &reddish_metal = boutique.add<rt::Metal>(rt::color{0.7, 0.6, 0.5});
-  world.primitives().add<rt::Sphere>(rt::point(0, 1, 0), 1.0, glass);
-  world.primitives().add<rt::Sphere>(rt::point(-4, 1, 0), 1.0, reddish);
-  world.primitives().add<rt::Sphere>(rt::point(4, 1, 0), 1.0, reddish_metal);
+  auto &glass = boutique.template add<rt::Dielectric>(1.5);
+  auto &reddish = boutique.template add<rt::Lambertian>(rt::color{0.4, 0.2, 0.1});
+  auto &reddish_metal = boutique.template add<rt::Metal>(rt::color{0.7, 0.6, 0.5});
+  world.primitives().template add<rt::Sphere>(rt::point(0, 1, 0), 1.0, glass);
+  world.primitives().template add<rt::Sphere>(rt::point(-4, 1, 0), 1.0, reddish);
+  world.primitives().template add<rt::Sphere>(rt::point(4, 1, 0), 1.0, reddish_metal);
   return world;
 }
+Scene lots_of_balls(const Config &cfg) { return lots_of_balls_on<Scene>(cfg); }
+VariantScene lots_of_balls_variant(const Config &cfg) { return lots_of_balls_on<VariantScene>(cfg); }
+WorldScene lots_of_balls_world(const Config &cfg) { return lots_of_balls_on<WorldScene>(cfg); }
 
 // Minimal Wavefront OBJ reader standing in for tinyobjloader 1.0.6 (not in this
 // image): vertex positions and the faces of the first shape.
@@ -122,14 +127,15 @@ static ObjMesh load_obj(const std::string &path, bool all_shapes) {
 }
 
 // src/main.cpp:85-136
-Scene foo(const Config &cfg) {
+template <class SceneT>
+static SceneT foo_on(const Config &cfg) {
   rt::random_int();
 
   rt::Camera cam{rt::point(1, 0, -1), rt::point(0, 0, 0), rt::vec3(0, 1, 0), 35.0,
                  cfg.aspect_ratio,    0.01,              std::nullopt,      0,
                  1};
-  rt::Scene world{cam};
-  auto &boring_material = world.boutique().add<rt::Lambertian>(rt::color{0.5, 0.5, 0.5});
+  SceneT world{cam};
+  auto &boring_material = world.boutique().template add<rt::Lambertian>(rt::color{0.5, 0.5, 0.5});
 
   // (RTOW_GENERAL_OBJ=1: the same for hosts that build scenes through rtow_host_scene_obj)
   const char *genv = std::getenv("RTOW_GENERAL_OBJ");
@@ -137,14 +143,14 @@ Scene foo(const Config &cfg) {
   const ObjMesh mesh = load_obj(cfg.model.value(), general);
   for (const auto &face : mesh.faces) {
     if (face.size() == 3) {
-      world.primitives().add<rt::Triangle>(mesh.vertices[face[0]], mesh.vertices[face[1]],
+      world.primitives().template add<rt::Triangle>(mesh.vertices[face[0]], mesh.vertices[face[1]],
                                            mesh.vertices[face[2]], boring_material);
     } else if (face.size() > 3) {
       // The reference calls tinyobj 1.0.6's LoadObj with its default triangulate = true
       // (src/main.cpp:109), so polygons reach its loop already cut into the fan (v0, vi, vi+1) and its
       // "isn't a triangle" branch (:130) is only reachable for faces of fewer than three vertices.
       for (size_t i = 1; i + 1 < face.size(); ++i)
-        world.primitives().add<rt::Triangle>(mesh.vertices[face[0]], mesh.vertices[face[i]],
+        world.primitives().template add<rt::Triangle>(mesh.vertices[face[0]], mesh.vertices[face[i]],
                                              mesh.vertices[face[i + 1]], boring_material);
     } else {
       throw std::runtime_error("Oops found a face that isn't a triangle");
@@ -153,5 +159,7 @@ Scene foo(const Config &cfg) {
   std::fprintf(stderr, "Scene has %zu triangles\n", world.primitives().size());
   return world;
 }
+Scene foo(const Config &cfg) { return foo_on<Scene>(cfg); }
+VariantScene foo_variant(const Config &cfg) { return foo_on<VariantScene>(cfg); }
 
 }  // namespace rtweekend::detail

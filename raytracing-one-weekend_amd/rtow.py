@@ -17,12 +17,13 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 LIB_PATH = Path(os.environ.get("RTOW_LIB", PKG_DIR / "librtow.so"))  # RTOW_LIB: A/B against another build
 
-RTOW_ABI_VERSION = 4
+RTOW_ABI_VERSION = 5
 RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY = 0, -1, -2, -3, -4, -5
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
 F64_STRICT, F64_FAST, F32 = 0, 1, 2
-KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH, KERNEL_GRID, KERNEL_BVH4 = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH, KERNEL_GRID, KERNEL_BVH4, KERNEL_REFTREE = 0, 1, 2, 3, 4, 5
+MODEL_OO, MODEL_VARIANT, MODEL_WORLD = 0, 1, 2  # scene models of the host scene scripts (include/rtow.h)
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1
 
 d3 = C.c_double * 3
@@ -101,6 +102,9 @@ EXPORTS = [
     "rtow_host_rng_reset", "rtow_host_ppm", "rtow_host_free", "rtow_tonemap_device",
     "rtow_profile_collect", "rtow_debug_counters", "rtow_render_rgb8",
     "rtow_ctx_set_builder", "rtow_build_info", "rtow_debug_image", "rtow_render_multi",
+    "rtow_debug_schedule", "rtow_host_scene_cover_model", "rtow_host_scene_obj_model",
+    "rtow_multi_create", "rtow_multi_set_builder", "rtow_multi_upload", "rtow_multi_build_info",
+    "rtow_multi_render", "rtow_multi_destroy",
 ]
 
 
@@ -143,6 +147,10 @@ def lib():
     L.rtow_host_scene_cover.argtypes = [C.POINTER(HostConfig), C.POINTER(C.POINTER(Scene))]
     L.rtow_host_scene_obj.argtypes = [C.POINTER(HostConfig), C.c_char_p,
                                       C.POINTER(C.POINTER(Scene))]
+    if hasattr(L, "rtow_host_scene_cover_model"):
+        L.rtow_host_scene_cover_model.argtypes = [C.POINTER(HostConfig), C.c_int32, C.POINTER(C.POINTER(Scene))]
+        L.rtow_host_scene_obj_model.argtypes = [C.POINTER(HostConfig), C.c_char_p, C.c_int32,
+                                                C.POINTER(C.POINTER(Scene))]
     L.rtow_host_scene_free.argtypes = [C.POINTER(Scene)]
     L.rtow_host_scene_free.restype = None
     L.rtow_host_rng_reset.restype = None
@@ -156,7 +164,18 @@ def lib():
     L.rtow_render_multi.argtypes = [C.c_int32, _pi, C.POINTER(Scene), C.POINTER(Config), _pd, C.POINTER(Stats),
                                     C.c_int32]
     L.rtow_debug_image.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
-    if L.rtow_abi_version() != RTOW_ABI_VERSION:
+    if hasattr(L, "rtow_multi_create"):
+        L.rtow_multi_create.argtypes = [C.c_int32, _pi, C.c_int32, C.POINTER(C.c_void_p)]
+        L.rtow_multi_set_builder.argtypes = [C.c_void_p, C.c_int32]
+        L.rtow_multi_upload.argtypes = [C.c_void_p, C.POINTER(Scene)]
+        L.rtow_multi_build_info.argtypes = [C.c_void_p, C.POINTER(BuildInfo)]
+        L.rtow_multi_render.argtypes = [C.c_void_p, C.POINTER(Config), _pd, C.POINTER(Stats)]
+        L.rtow_multi_destroy.argtypes = [C.c_void_p]
+        L.rtow_multi_destroy.restype = None
+    if hasattr(L, "rtow_debug_schedule"):  # (absent from older builds loaded through RTOW_LIB for A/B runs)
+        L.rtow_debug_schedule.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(C.c_uint32), C.c_int32]
+    ver = L.rtow_abi_version()
+    if ver != RTOW_ABI_VERSION and not ("RTOW_LIB" in os.environ and ver >= 4):  # (older builds: A/B runs only)
         raise RtowError("librtow.so ABI version mismatch")
     _lib = L
     return L
@@ -208,24 +227,31 @@ class HostScene:
         return self.ptr.contents
 
     @classmethod
-    def cover(cls, nsqrt=11, aspect=1.5, moving=False, reset_rng=True):
+    def cover(cls, nsqrt=11, aspect=1.5, moving=False, reset_rng=True, model=MODEL_OO):
+        """`model`: which of the reference's scene models the script builds (MODEL_OO / _VARIANT / _WORLD)."""
         L = lib()
         if reset_rng:
             L.rtow_host_rng_reset()
         hc = HostConfig(nsqrt, aspect, int(moving))
         out = C.POINTER(Scene)()
-        check(L.rtow_host_scene_cover(C.byref(hc), C.byref(out)), "rtow_host_scene_cover")
+        if model == MODEL_OO:
+            check(L.rtow_host_scene_cover(C.byref(hc), C.byref(out)), "rtow_host_scene_cover")
+        else:
+            check(L.rtow_host_scene_cover_model(C.byref(hc), model, C.byref(out)), "rtow_host_scene_cover_model")
         return cls(out)
 
     @classmethod
-    def obj(cls, path, aspect=16.0 / 9.0, reset_rng=True):
+    def obj(cls, path, aspect=16.0 / 9.0, reset_rng=True, model=MODEL_OO):
         L = lib()
         if reset_rng:
             L.rtow_host_rng_reset()
         hc = HostConfig(0, aspect, 0)
         out = C.POINTER(Scene)()
-        check(L.rtow_host_scene_obj(C.byref(hc), str(path).encode(), C.byref(out)),
-              "rtow_host_scene_obj")
+        if model == MODEL_OO:
+            check(L.rtow_host_scene_obj(C.byref(hc), str(path).encode(), C.byref(out)), "rtow_host_scene_obj")
+        else:
+            check(L.rtow_host_scene_obj_model(C.byref(hc), str(path).encode(), model, C.byref(out)),
+                  "rtow_host_scene_obj_model")
         return cls(out)
 
     def close(self):
@@ -336,6 +362,46 @@ def render_multi(device_ids, scene, cfg: Config, use_rccl=True):
     check(lib().rtow_render_multi(len(device_ids), ids, C.byref(s), C.byref(cfg), out.ctypes.data_as(_pd), C.byref(st),
                                   int(bool(use_rccl))), "rtow_render_multi")
     return out, st
+
+
+class MultiContext:
+    """Persistent multi-device handle (rtow_multi_*): contexts, streams, buffers, worker threads and the RCCL
+    communicator live as long as the object; upload once, render many frames."""
+
+    def __init__(self, device_ids, use_rccl=True):
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        check(lib().rtow_multi_create(len(device_ids), ids, int(bool(use_rccl)), C.byref(self._h)), "rtow_multi_create")
+        self.n = len(device_ids)
+
+    def upload(self, scene):
+        s = scene.c if isinstance(scene, HostScene) else scene
+        check(lib().rtow_multi_upload(self._h, C.byref(s)), "rtow_multi_upload")
+
+    def build_info(self) -> BuildInfo:
+        bi = BuildInfo()
+        check(lib().rtow_multi_build_info(self._h, C.byref(bi)), "rtow_multi_build_info")
+        return bi
+
+    def render(self, cfg: Config, want_stats=True):
+        import numpy as np
+
+        out = np.zeros((cfg.image_height, cfg.image_width, 3), dtype=np.float64)
+        st = Stats() if want_stats else None
+        check(lib().rtow_multi_render(self._h, C.byref(cfg), out.ctypes.data_as(_pd),
+                                      C.byref(st) if st is not None else None), "rtow_multi_render")
+        return out, st
+
+    def close(self):
+        if self._h:
+            lib().rtow_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def have_gpu() -> bool:

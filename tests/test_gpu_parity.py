@@ -653,3 +653,64 @@ def test_build_defaults_that_the_measured_numbers_rest_on():
         assert struct.unpack_from("<I", img, 60)[0] == (80 if moving else 48)  # fat lists still fit
         assert len(img) <= 160 * 1024
     c.close()
+
+
+def test_variant_and_world_scene_models_render_like_the_oracle(ctx):
+    """scenes built on the reference's other two models (variant primitives,
+    src/variant-primitives.h; the World of src/vmodel.h) through the product's host API render, strict
+    build, to the oracle's image bit for bit — in the library and through `rtweekend --primitives`."""
+    import subprocess
+
+    from conftest import REPO
+
+    scene_ref = orc.OrcScene.cover(5, 1.5, True)
+    cfg = rtow.make_config(96, 64, 6, 3, 20, seed=31, precision=rtow.F64_STRICT)
+    ref, ost = orc.render(scene_ref, cfg, orc.RNG_PHILOX, nthreads=4)
+    for model in (rtow.MODEL_VARIANT, rtow.MODEL_WORLD):
+        scene = rtow.HostScene.cover(5, 1.5, True, model=model)
+        img, st = ctx.render(scene, cfg)
+        assert np.array_equal(img, ref), model
+        assert st.segments == ost.segments
+    mesh_ref = orc.OrcScene.obj(GOLDEN / "suzanne.obj", 16 / 9)
+    mcfg = rtow.make_config(64, 36, 4, 2, 20, seed=5, precision=rtow.F64_STRICT)
+    mref, _ = orc.render(mesh_ref, mcfg, orc.RNG_PHILOX, nthreads=4)
+    mimg, _ = ctx.render(rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9, model=rtow.MODEL_VARIANT), mcfg)
+    assert np.array_equal(mimg, mref)
+    exe = REPO / "raytracing-one-weekend_amd" / "rtweekend"
+    args = ["-w", "96", "-a", "1.5", "-s", "6", "-t", "3", "-c", "20", "-n", "5", "-m", "--seed", "31",
+            "--precision", "strict"]
+    want = orc.ppm_text(ref, 96, 64, 6)
+    for flag in ("oo", "variant", "world"):
+        r = subprocess.run([str(exe)] + args + ["--primitives", flag], capture_output=True, check=True)
+        assert r.stdout == want, flag
+    r = subprocess.run([str(exe), "-l", str(GOLDEN / "suzanne.obj"), "--primitives", "world", "-w", "32"],
+                       capture_output=True)
+    assert r.returncode == 1 and b"spheres only" in r.stderr
+
+
+def test_fast_build_image_does_not_depend_on_nstreams(ctx):
+    """Fast builds: the work items follow a schedule over the sample range, not Config::nthreads
+    (include/rtow.h, rtow_debug_schedule): the same effective spp gives the same image bit for bit whatever
+    nstreams is — a drop-in caller with the reference's default of 4 threads gets the bench's kernel — and it
+    stays within the fast build's tolerance of the strict image (which does follow nstreams)."""
+    import ctypes as C
+
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    imgs = []
+    for ns in (1, 4, 12):
+        cfg = rtow.make_config(240, 160, 48, ns, 50, seed=5, precision=rtow.F64_FAST)
+        imgs.append(ctx.render(scene, cfg)[0])
+        pairs = (C.c_uint32 * 128)()
+        n = rtow.lib().rtow_debug_schedule(ctx._h, C.byref(cfg), pairs, 64)
+        sched = [(pairs[2 * i], pairs[2 * i + 1]) for i in range(n)]
+        assert sum(c for _, c in sched) == 48 and sched[0][0] == 0 and sched[-1][1] == 1
+        assert all(a + c == b for (a, c), (b, _) in zip(sched, sched[1:]))  # contiguous sample ranges
+        assert max(c for _, c in sched) <= 16
+    assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
+    strict, _ = ctx.render(scene, rtow.make_config(240, 160, 48, 4, 50, seed=5, precision=rtow.F64_STRICT))
+    assert np.abs(imgs[0] - strict).mean() / 48 <= 1e-4
+    # a stream range is scheduled over its own samples: two accumulated halves stay within the same tolerance
+    full = imgs[1]
+    half = ctx.render(scene, rtow.make_config(240, 160, 48, 4, 50, seed=5, precision=rtow.F64_FAST, stream_first=0,
+                                               stream_count=2))[0]
+    assert np.abs(half - full).mean() / 48 > 1e-3  # (really half the samples)

@@ -36,6 +36,34 @@ def test_cover_scene_flattens_like_the_oracle(moving):
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("moving", [False, True])
+def test_variant_store_and_world_flatten_like_the_oo_scene(moving):
+    """the reference's other two scene models — VariantStore primitives
+    (src/variant-primitives.h:84-113) and the World of src/vmodel.h:250-253 — built by the same calls of
+    lots_of_balls() flatten to the rtow_scene_t of the OO scene, record for record."""
+    oo_scene = rtow.HostScene.cover(11, 1.5, moving)  # (kept alive: scene_arrays are views)
+    oo = orc.scene_arrays(oo_scene.c)
+    for model in (rtow.MODEL_VARIANT, rtow.MODEL_WORLD):
+        other = rtow.HostScene.cover(11, 1.5, moving, model=model)
+        assert other.c.n_prims == (485 if moving else 486)
+        b = orc.scene_arrays(other.c)
+        assert set(b) == set(oo)
+        for k in oo:
+            assert np.array_equal(oo[k], b[k]), (model, k)
+
+
+def test_variant_store_obj_scene_and_world_refusal():
+    oo_scene = rtow.HostScene.obj(GOLDEN / "suzanne.obj")
+    oo = orc.scene_arrays(oo_scene.c)
+    var = rtow.HostScene.obj(GOLDEN / "suzanne.obj", model=rtow.MODEL_VARIANT)
+    assert var.c.n_triangles == 968
+    b = orc.scene_arrays(var.c)
+    for k in oo:
+        assert np.array_equal(oo[k], b[k]), k
+    with pytest.raises(rtow.RtowError):  # src/vmodel.h's World = VariantStore<Sphere, MovingSphere>: no triangles
+        rtow.HostScene.obj(GOLDEN / "suzanne.obj", model=rtow.MODEL_WORLD)
+
+
 def test_obj_scene_flattens_like_the_oracle():
     mine = rtow.HostScene.obj(GOLDEN / "suzanne.obj")
     ref = orc.OrcScene.obj(GOLDEN / "suzanne.obj")
@@ -166,3 +194,40 @@ def test_product_path_fails_loudly_without_a_hip_device():
         b = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "1", "--warmup", "0"] + extra,
                            capture_output=True)
         assert b.returncode != 0 and b"HIP device" in b.stderr and b"n_gpus" not in b.stdout
+
+
+def _schedule(cfg):
+    pairs = (C.c_uint32 * 4096)()
+    n = rtow.lib().rtow_debug_schedule(None, C.byref(cfg), pairs, 2048)
+    assert n >= 0
+    return [(pairs[2 * i], pairs[2 * i + 1]) for i in range(n)]
+
+
+@pytest.mark.parametrize("spp,ns", [(100, 10), (100, 4), (500, 4), (7, 3), (1, 1), (16, 1), (1024, 64)])
+def test_fast_build_schedule_properties(spp, ns, monkeypatch):
+    """The levels a fast-build render is cut into (pure host arithmetic): they tile the effective sample
+    range, do not depend on nstreams beyond the effective spp, are at most RTOW_SCHED_CHUNK long, end on a
+    single sample, and from the shrinking part on no level is longer than the work queued behind it."""
+    for k in ("RTOW_SCHED_CHUNK", "RTOW_SCHED_RATIO"):
+        monkeypatch.delenv(k, raising=False)
+    eff = spp // ns * ns
+    cfg = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST)
+    s = _schedule(cfg)
+    assert s[0][0] == 0 and sum(c for _, c in s) == eff
+    assert all(a + c == b for (a, c), (b, _) in zip(s, s[1:]))
+    assert all(1 <= c <= 16 for _, c in s) and s[-1][1] == 1
+    counts = [c for _, c in s]
+    for i, c in enumerate(counts[:-1]):
+        if c < 16 and i > 0:  # (the first level may be the short remainder)
+            assert c <= max(1, sum(counts[i + 1:])), (i, counts)
+    # the same effective spp through another stream count: the same table
+    other = rtow.make_config(64, 48, eff, 1, 10, precision=rtow.F64_FAST)
+    assert _schedule(other) == s
+    # strict build: one level per stream, the reference's decomposition (src/render.cpp:169-185)
+    strict = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_STRICT)
+    assert _schedule(strict) == [(k * (spp // ns), spp // ns) for k in range(ns)]
+    # a stream range covers its own samples
+    if ns >= 2:
+        part = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST, stream_first=1, stream_count=ns - 1)
+        ps = _schedule(part)
+        assert ps[0][0] == spp // ns and sum(c for _, c in ps) == (ns - 1) * (spp // ns)

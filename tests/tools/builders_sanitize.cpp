@@ -72,6 +72,25 @@ int main(int argc, char **argv) {
     std::printf("  pair leaves: %d BVH4 nodes, depth %d, %zu bytes\n", v.n_nodes, v.depth, v.blob.size());
     tri.insert(tri.end(), tri.begin(), tri.begin() + 12 * 50);  // second round: 50 coincident triangles
   }
+  {  // concurrent subtrees (forced on this small mesh), a build whose every thread start fails, and the serial
+     // build: one tree, byte-identical images (the advisor's finding on std::async across the C ABI)
+    const size_t nt = tri.size() / 12;
+    std::vector<int32_t> pmat(nt, 0);
+    std::vector<double> none;
+    std::vector<unsigned char> ref;
+    for (int mode = 0; mode < 3; ++mode) {
+      rtow::HostBvh bvh;
+      rtow::build_bvh(none, none, none, tri, bvh, 2, 1.5, 0.0, 1.0, mode == 0 ? (1 << 30) : 64, mode == 2 ? 1 : 0);
+      rtow::SceneImage img;
+      rtow::make_scene_image(bvh, none, none, tri, cam, img, pmat, mats);
+      if (!rtow::validate_scene_image(img, (int)nt)) return 70 + mode;
+      if (mode == 0)
+        ref = img.blob;
+      else if (img.blob != ref)
+        return 73 + mode;
+    }
+    std::printf("serial, concurrent and thread-start-failure builds give one image (%zu bytes)\n", ref.size());
+  }
   {  // one triangle: a single-leaf tree
     std::vector<double> one(tri.begin(), tri.begin() + 12), none;
     std::vector<int32_t> pmat(1, 0);
