@@ -70,6 +70,14 @@ extern "C" {
                                first, with a per-lane stack in LDS; the image (or the top of
                                its tree) is staged in LDS.  Falls back to BVH for scenes with
                                spheres, for the f32 preview build and for the device builder */
+#define RTOW_KERNEL_REFTREE 5 /* opt-in exactness mode (RTOW_F64_STRICT only): every lane walks the REFERENCE's own
+                               tree — median split of the insertion-ordered primitive array, leaves of 1..6 whose
+                               boxes include the origin, float-rounded triangle boxes, signed-radius sphere boxes
+                               (src/render.cpp:73-110, src/common-model.cpp:127-134,168-207) — left before right with
+                               the reference's f64 Aabb::hit (src/common-model.h:71-84, `t_max <= t_min` rejects).
+                               The other kernels give the reference's image wherever its tree finds the closest hit;
+                               this one also where it does not (flat leaf boxes, coordinates beyond float precision,
+                               negative radii, exact ties).  Never chosen by RTOW_KERNEL_AUTO: it is slow */
 
 /* Camera state: exactly the private members of the reference Camera after its
  * constructor ran (src/common-model.h:104-112, src/common-model.cpp:136-154). */
@@ -206,6 +214,12 @@ typedef struct rtow_build_info_t {
   double upload_ms;         /* whole rtow_scene_upload call */
   int32_t bvh4_nodes;       /* 4-wide BVH image (triangle meshes, host builder): nodes, 0 = none */
   int32_t bvh4_image_bytes;
+  /* RTOW_KERNEL_REFTREE (built at the first render that asks for it; 0 before): nodes of the reference's
+   * tree and its "Total BVH stupid volume" diagnostic (src/render.cpp:36-50,148) */
+  int32_t ref_tree_nodes;
+  int32_t pad_;
+  double ref_tree_stupid_volume;
+  double ref_tree_build_ms;
 } rtow_build_info_t;
 /* Facts about the last rtow_scene_upload of this context. */
 int rtow_build_info(rtow_ctx *ctx, rtow_build_info_t *out);

@@ -23,6 +23,7 @@
 #include "rtow_bvh4.h"
 #include "rtow_device.h"
 #include "rtow_grid.h"
+#include "rtow_reftree.h"
 
 namespace {
 
@@ -307,6 +308,14 @@ struct rtow_ctx {
   void *lbvh_scratch = nullptr;  // device builder's buffers, kept across uploads
   void *grid_scratch = nullptr;
   rtow_build_info_t build_info{};
+  // RTOW_KERNEL_REFTREE: the reference's own tree is built on first use from a host copy of the scene as uploaded
+  struct HostSceneCopy {
+    std::vector<double> sg, mg, tg;
+    std::vector<int32_t> pk, pi;
+    bool have_order = false;
+  } host_scene;
+  DevBuf rtree;
+  bool have_rtree = false;
   // workspace
   DevBuf partials, stack, counters, spill;
   DevBuf out, out8;  // rtow_render / rtow_render_rgb8: device-side output of the host-buffer entry points
@@ -318,7 +327,7 @@ struct rtow_ctx {
   std::vector<uint32_t> lvl_host;
   long long lvl_key[4] = {-1, -1, -1, -1};
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
-  int occ[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  int occ[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
   hipEvent_t ev[kEventRing][2] = {};
   int ev_count = 0;
@@ -371,7 +380,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
-                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->lvl_dev})
+                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->lvl_dev, &c->rtree})
     b->release();
   if (c->lvl_pinned) (void)hipHostFree(c->lvl_pinned);
   for (int i = 0; i < kEventRing; ++i)
@@ -418,7 +427,30 @@ static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipDeviceSynchronize());
   c->have_scene = false;
+  c->have_rtree = false;
+  c->build_info.ref_tree_nodes = 0;
+  c->build_info.ref_tree_stupid_volume = 0.0;
   const double t_up0 = now_ms();
+  {
+    rtow_ctx::HostSceneCopy &h = c->host_scene;
+    h.sg.assign(s->sphere_geom, s->sphere_geom + 4 * (size_t)s->n_spheres);
+    h.mg.assign(s->moving_geom, s->moving_geom + 8 * (size_t)s->n_moving);
+    h.tg.assign(s->triangle_geom, s->triangle_geom + 9 * (size_t)s->n_triangles);
+    h.have_order = s->prim_kind && s->prim_index;
+    if (h.have_order) {
+      for (int i = 0; i < s->n_prims; ++i) {
+        const int k = s->prim_kind[i], ix = s->prim_index[i];
+        const int cnt = k == RTOW_PRIM_SPHERE ? s->n_spheres : k == RTOW_PRIM_MOVING_SPHERE ? s->n_moving
+                        : k == RTOW_PRIM_TRIANGLE ? s->n_triangles : -1;
+        if (ix < 0 || ix >= cnt) return fail(RTOW_EINVAL, "prim_kind / prim_index entry %d out of range", i);
+      }
+      h.pk.assign(s->prim_kind, s->prim_kind + s->n_prims);
+      h.pi.assign(s->prim_index, s->prim_index + s->n_prims);
+    } else {
+      h.pk.clear();
+      h.pi.clear();
+    }
+  }
 
   // Ray-independent terms, computed with the reference's operations (this file is
   // built with -ffp-contract=off, so each is one IEEE operation, as on the CPU).
@@ -639,7 +671,7 @@ static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     if (!grid_on_device && (rc = upload(c->gblob, gimg.blob))) return rc;
     c->gblob_bytes = (uint32_t)(grid_on_device ? gimg.total_bytes : gimg.blob.size());
   }
-  for (auto &o : c->occ) o[0] = o[1] = o[2] = o[3] = 0;
+  for (auto &o : c->occ) o[0] = o[1] = o[2] = o[3] = o[4] = 0;
 
   rtow::DevScene &ds = c->ds;
   ds.sph = (const double *)c->sph.p;
@@ -757,7 +789,7 @@ static int validate_cfg(const rtow_config_t *cfg) {
   if (cfg->tile_rows <= 0) return fail(RTOW_EINVAL, "tile_rows must be >= 1");
   if (cfg->precision != RTOW_F64_STRICT && cfg->precision != RTOW_F64_FAST && cfg->precision != RTOW_F32)
     return fail(RTOW_EINVAL, "unknown precision %d", cfg->precision);
-  if (cfg->kernel < RTOW_KERNEL_AUTO || cfg->kernel > RTOW_KERNEL_BVH4)
+  if (cfg->kernel < RTOW_KERNEL_AUTO || cfg->kernel > RTOW_KERNEL_REFTREE)
     return fail(RTOW_EINVAL, "unknown kernel %d", cfg->kernel);
   if ((long long)cfg->image_width * cfg->image_height > 0x7fffffffLL)
     return fail(RTOW_EINVAL, "image too large");
@@ -986,17 +1018,47 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
              : bvh4_ok ? RTOW_KERNEL_BVH4 : RTOW_KERNEL_BVH;
   if (kernel == RTOW_KERNEL_GRID && !c->have_grid) kernel = RTOW_KERNEL_BVH;  // scene not suited to a grid
   if (kernel == RTOW_KERNEL_BVH4 && !bvh4_ok) kernel = RTOW_KERNEL_BVH;
+  if (kernel == RTOW_KERNEL_REFTREE) {
+    // the reference's own tree and box test: an exactness mode, so it exists in the strict build only
+    if (!strict) return fail(RTOW_EINVAL, "RTOW_KERNEL_REFTREE needs precision RTOW_F64_STRICT");
+    if (!c->have_rtree) {
+      rtow_scene_t hs;
+      std::memset(&hs, 0, sizeof hs);
+      const rtow_ctx::HostSceneCopy &h = c->host_scene;
+      hs.n_spheres = c->ds.n_sph;
+      hs.n_moving = c->ds.n_mov;
+      hs.n_triangles = c->ds.n_tri;
+      hs.n_prims = c->n_prims;
+      hs.sphere_geom = h.sg.data();
+      hs.moving_geom = h.mg.data();
+      hs.triangle_geom = h.tg.data();
+      hs.prim_kind = h.have_order ? h.pk.data() : nullptr;
+      hs.prim_index = h.have_order ? h.pi.data() : nullptr;
+      rtow::RefTree rt;
+      const double t0 = now_ms();
+      rtow::build_reftree(&hs, rt);
+      if (!rt.ok) return fail(RTOW_EINVAL, "reference tree: depth %d exceeds the kernel's stack", rt.depth);
+      if ((rc = upload(c->rtree, rt.blob))) return rc;
+      c->ds.rtree = (const unsigned char *)c->rtree.p;
+      c->ds.rt_off_ids = rt.off_ids;
+      c->have_rtree = true;
+      c->build_info.ref_tree_nodes = rt.n_nodes;
+      c->build_info.ref_tree_stupid_volume = rt.stupid_volume;
+      c->build_info.ref_tree_build_ms = now_ms() - t0;
+    }
+  }
   rtow::DevScene scene = f32 ? c->ds32 : c->ds;
-  int block = kernel >= RTOW_KERNEL_BVH ? kBvhBlock : kBlock;
-  if (kernel >= RTOW_KERNEL_BVH && c->knobs.bvh_block) block = c->knobs.bvh_block;  // experiment knob
+  int block = (kernel >= RTOW_KERNEL_BVH && kernel <= RTOW_KERNEL_BVH4) ? kBvhBlock : kBlock;
+  const bool image_kernel = kernel >= RTOW_KERNEL_BVH && kernel <= RTOW_KERNEL_BVH4;
+  if (image_kernel && c->knobs.bvh_block) block = c->knobs.bvh_block;  // experiment knob
   // the scene image goes to LDS when one copy per workgroup fits (160 KiB per CU)
   const uint32_t image_bytes = kernel == RTOW_KERNEL_GRID ? scene.gblob_bytes : scene.blob_bytes;
   // an image too big for two workgroups per CU: ONE 1024-lane workgroup (16 waves, the same 4 per SIMD)
   // instead of one 512-lane workgroup (2 per SIMD)
-  if (kernel >= RTOW_KERNEL_BVH && block == kBvhBlock && image_bytes <= kLdsLimit && 2u * image_bytes > kLdsLimit &&
+  if (image_kernel && block == kBvhBlock && image_bytes <= kLdsLimit && 2u * image_bytes > kLdsLimit &&
       !c->knobs.bvh_block)
     block = 1024;
-  unsigned lds_bytes = (kernel >= RTOW_KERNEL_BVH && image_bytes <= kLdsLimit) ? image_bytes : 0u;
+  unsigned lds_bytes = (image_kernel && image_bytes <= kLdsLimit) ? image_bytes : 0u;
   int stack_bound = 0;
   if (kernel == RTOW_KERNEL_BVH4) {
     // One 1024-lane workgroup per CU.  LDS = [image, or the top of its tree][stack: K entries x 4 B per lane].
@@ -1165,7 +1227,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
   if (slot >= 0) HIPCHK(hipEventRecord(c->ev[slot][0], st));
   int launch_kernel = kernel;
-  if (kernel >= RTOW_KERNEL_BVH && lds_bytes > 0 && c->knobs.stamps) launch_kernel = kernel + 16;  // diagnostic
+  if (image_kernel && lds_bytes > 0 && c->knobs.stamps) launch_kernel = kernel + 16;  // diagnostic
   int lrc = strict ? rtow::launch_trace_strict(P, launch_kernel, (int)grid, block, lds_bytes, st)
             : f32  ? rtow::launch_trace_f32(P, launch_kernel, (int)grid, block, lds_bytes, st)
                    : rtow::launch_trace_fast(P, launch_kernel, (int)grid, block, lds_bytes, st);

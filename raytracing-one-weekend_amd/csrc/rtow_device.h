@@ -68,7 +68,13 @@ struct DevScene {
   uint32_t b4_aux_src, b4_aux_lds;
   uint32_t b4_stack_base;  // LDS byte offset of the traversal stack ([entry][lane of the workgroup], 4 B each)
   uint32_t b4_stack_k;     // entries per lane in LDS; deeper entries go to TraceParams::spill
+  // the reference's own tree (rtow_reftree.h; kernel RTOW_KERNEL_REFTREE): [nodes x 64 B][ids], in global memory
+  const unsigned char *rtree;
+  uint32_t rt_off_ids;
 };
+constexpr uint32_t kRefNodeBytes = 64;
+constexpr uint32_t kRefLeafFlag = 0x80000000u;
+constexpr int kRefStackDepth = 48;
 
 struct FastDiv {  // unsigned division by a per-launch constant (see fastdiv() in the kernel)
   uint32_t magic, shift;

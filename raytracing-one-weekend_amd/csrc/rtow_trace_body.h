@@ -74,6 +74,9 @@ namespace {
 #include "rtow_trace_bvh.h"
 #include "rtow_trace_grid.h"
 #include "rtow_trace_bvh4.h"
+#ifndef RTOW_FAST_MATH
+#include "rtow_trace_reftree.h"
+#endif
 
 // --------------------------------------------------------------- the kernel ---
 // n / d for a divisor fixed per launch: q = (((n - t) >> 1) + t) >> shift, t = mulhi(n, magic)
@@ -387,7 +390,7 @@ __device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, in
 // KERNEL: 1 = STREAM, 2 = BVH, 3 = GRID, 4 = BVH4;  LDS: scene image staged in LDS (2 and 3; the
 // BVH4 kernel always uses LDS: the image or its top, and the traversal stack)
 template <int KERNEL, bool LDS, bool STAMPS = false>
-__global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
+__global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const TraceParams P) {
   const DevScene &sc = P.sc;
   const uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
@@ -648,7 +651,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
         m_fuzz = (real)m1.y;
         m_ir = (real)m2.x;
         kind = (int)(__double_as_longlong(m2.y) & 0xffffffffll);
-      } else if constexpr (KERNEL >= 2) {
+      } else if constexpr (KERNEL >= 2 && KERNEL <= 4) {
         const uint32_t o_sph = KERNEL == 3 ? sc.g_off_sph : sc.off_sph;
         const uint32_t o_mov = KERNEL == 3 ? sc.g_off_mov : sc.off_mov;
         const uint32_t o_tri = KERNEL == 3 ? sc.g_off_tri : sc.off_tri;
@@ -880,6 +883,10 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
     } else if constexpr (KERNEL == 2) {
       // the walk uses wave votes, so every lane of the wave enters it
       best = closest_hit_bvh<LDS, STAMPS>(im, sc, ro, rd, rtime, tracing, nnode, nprim, stamps);
+    } else if constexpr (KERNEL == 5) {
+#ifndef RTOW_FAST_MATH
+      if (tracing) best = closest_hit_reftree(sc, to_f64(ro), to_f64(rd), (double)rtime, nnode, nprim);
+#endif
     } else {
       if (tracing) best = closest_hit_stream(sc, to_f64(ro), to_f64(rd), (double)rtime);
     }
@@ -909,7 +916,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 ? 1024 : 256)
             const uint32_t mr = sc.b4_off_mats + 48u * smi;
             const vd2 a0 = im4.d2(mr), a1 = im4.d2(mr + 16u);
             c = V3{(real)a0.x, (real)a0.y, (real)a1.x} * c;
-          } else if constexpr (KERNEL >= 2) {
+          } else if constexpr (KERNEL >= 2 && KERNEL <= 4) {
             const uint32_t mr = (KERNEL == 3 ? sc.g_off_mats : sc.off_mats) + 48u * smi;
             const double2 a0 = im.d2(mr), a1 = im.d2(mr + 16u);
             c = V3{(real)a0.x, (real)a0.y, (real)a1.x} * c;
@@ -1042,6 +1049,9 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
                   : (stamps ? launch_sm4<false, true>(p, grid, block, lds_bytes, st)
                             : launch_sm4<false, false>(p, grid, block, lds_bytes, st));
     }
+#ifndef RTOW_FAST_MATH
+    case 5: return launch_one<5, false, false>(p, grid, block, 0, st);  // the reference's tree: strict build only
+#endif
     case 2 + 16: return launch_one<2, true, true>(p, grid, block, lds_bytes, st);
     case 3 + 16: return launch_one<3, true, true>(p, grid, block, lds_bytes, st);
     default: return (int)hipErrorInvalidValue;
@@ -1056,6 +1066,11 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
 int RTOW_CAT(trace_occupancy_, RTOW_SUFFIX)(int kernel, int block, unsigned lds_bytes) {
   const void *fn;
   const bool lds = lds_bytes > 0;
+#ifndef RTOW_FAST_MATH
+  if (kernel == 5)
+    fn = reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<5, false, false>);
+  else
+#endif
   if (kernel == 4)  // (both variants have the same launch bounds; the full-LDS one stands for both)
     fn = reinterpret_cast<const void *>(RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<4, true, false>);
   else if (kernel == 3)

@@ -324,6 +324,9 @@ static void render_flat(FlatScene *flat, const Config &cfg) {
   }
 
   auto took = khr::high_resolution_clock::now() - start;
+  if (bi.ref_tree_nodes > 0)  // --kernel reftree: the reference's own tree and its diagnostic (src/render.cpp:148)
+    std::cerr << "Total BVH stupid volume: " << bi.ref_tree_stupid_volume << "\n"
+              << "Reference tree: " << bi.ref_tree_nodes << " nodes, built in " << bi.ref_tree_build_ms << " ms\n";
   std::cerr << "BVH image: " << bi.bvh_nodes << " nodes, " << bi.bvh_image_bytes << " bytes, built on the "
             << (bi.builder == RTOW_BUILDER_DEVICE_LBVH ? "device (LBVH)" : "host (SAH)") << " in " << bi.bvh_build_ms
             << " ms\n";

@@ -80,6 +80,11 @@ def device_images(ctx, sc, cfgargs, kernels=KERNELS):
     return out[0]
 
 
+def reftree_image(ctx, sc, cfgargs):
+    """The opt-in kernel that walks the reference's own tree (RTOW_KERNEL_REFTREE, strict build)."""
+    return ctx.render(sc, rtow.make_config(*cfgargs, precision=rtow.F64_STRICT, kernel=rtow.KERNEL_REFTREE))
+
+
 def test_zero_thickness_leaf_box_the_reference_never_hits_a_flat_leaf(ctx):
     """SURVEY §8 a5: Aabb::hit rejects with `t_max <= t_min` (src/common-model.h:80), and a leaf's box is
     the union of its primitives' boxes with the default box at the origin (src/render.cpp:76-78).  A
@@ -94,6 +99,8 @@ def test_zero_thickness_leaf_box_the_reference_never_hits_a_flat_leaf(ctx):
     assert ost.segments == ost.samples  # the reference: every ray misses, pure sky
     img, st = device_images(ctx, flat, args, kernels=TRI_KERNELS)
     assert st.segments > st.samples and not np.array_equal(img, ref)  # the device: the triangle is there
+    rimg, rst = reftree_image(ctx, flat, args)  # ... unless it is told to walk the reference's tree
+    assert np.array_equal(rimg, ref) and rst.segments == ost.segments
     # the device image is what the reference's own hit test gives once its box has thickness:
     # the same triangle and camera translated by +0.25 in z (exactly representable)
     cam2 = camera((0.3, 0.2, 3.25), (0, 0, 0.25), (0, 1, 0), 40.0, 1.5)
@@ -130,6 +137,8 @@ def test_exact_ties_in_t_resolve_like_the_reference_leaf_scan(ctx):
                 b, bst = ctx.render(sc, rtow.make_config(*args, precision=rtow.F64_STRICT, kernel=k))
                 assert bst.segments == ost.segments
                 bvh.append(b)
+            rimg, rst = reftree_image(ctx, sc, args)  # the reference's own leaf order: its winner, in every case
+            assert np.array_equal(rimg, ref) and rst.segments == ost.segments
             refs.append(ref)
         assert not np.array_equal(refs[0], refs[1])  # the winner really is the later one
         for b in bvh:
@@ -171,7 +180,53 @@ def test_float_rounded_triangle_box_drops_a_stripe_in_the_reference(ctx):
     # everywhere else the rays enter the reference's box and both sides agree bit for bit
     diff = np.any(img != ref, axis=(0, 2))
     assert diff[56:63].any() and not diff[:55].any() and not diff[64:].any()
+    rimg, rst = reftree_image(ctx, sc, args)  # the reference's float-rounded box: its stripe missing too
+    assert np.array_equal(rimg, ref) and rst.segments == ost.segments
     sc1, keep1 = build(-1.0)
     ref1, ost1 = orc.render(sc1, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
     img1, st1 = device_images(ctx, sc1, args, kernels=(rtow.KERNEL_BRUTE, rtow.KERNEL_BVH, rtow.KERNEL_BVH4))
     assert np.array_equal(img1, ref1) and st1.segments == ost1.segments
+
+
+def test_reference_tree_kernel_equals_the_oracles_reference_tree_everywhere(ctx):
+    """RTOW_KERNEL_REFTREE against the oracle's restatement of the reference tree (accel = 0: its median-split
+    build, boxes and Aabb::hit), bit for bit, on the reference's own scene classes (sort ties and all), on a
+    negative-radius sphere (signed-radius box, src/common-model.cpp:168-171: the reference's own tree loses the
+    hollow sphere's far side where the default kernels keep it) and through the `rtweekend` CLI; the tree's
+    "stupid volume" diagnostic equals the survey's numbers for the reference."""
+    import subprocess
+
+    from conftest import GOLDEN, REPO
+
+    cases = [(rtow.HostScene.cover(11, 1.5, False), orc.OrcScene.cover(11, 1.5, False), (120, 80, 4, 2, 50, 7), 2150.93),
+             (rtow.HostScene.cover(11, 1.5, True), orc.OrcScene.cover(11, 1.5, True), (120, 80, 4, 2, 50, 8), None),
+             (rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9), orc.OrcScene.obj(GOLDEN / "suzanne.obj", 16 / 9),
+              (96, 54, 4, 2, 20, 9), 34.6011)]
+    for scene, oscene, args, volume in cases:
+        ref, ost = orc.render(oscene, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
+        img, st = reftree_image(ctx, scene, args)
+        assert np.array_equal(img, ref) and st.segments == ost.segments
+        assert st.kernel_used == rtow.KERNEL_REFTREE
+        # the reference's walk visits what the oracle's walk visits
+        assert st.node_tests == ost.node_tests and st.prim_tests == ost.prim_tests
+        if volume is not None:
+            assert abs(ctx.build_info().ref_tree_stupid_volume - volume) < 5e-3 * max(1.0, volume / 1000)
+    # negative radius: glass shell (outer r = 0.5, inner r = -0.45) over a ground sphere
+    cam = camera((0, 0.4, 3.0), (0, 0, 0), (0, 1, 0), 35.0, 1.5)
+    glass = (rtow.MAT_DIELECTRIC, (1, 1, 1), 0.0, 1.5)
+    sc, keep = scene_of(cam, spheres=[(0, -100.5, 0, 100, 0), (0, 0, 0, 0.5, 1), (0, 0, 0, -0.45, 1)],
+                        materials=[LAMB((0.8, 0.8, 0.0)), glass])
+    args = (90, 60, 8, 2, 20, 4)
+    ref, ost = orc.render(sc, rtow.make_config(*args), orc.RNG_PHILOX, nthreads=4)
+    img, st = reftree_image(ctx, sc, args)
+    assert np.array_equal(img, ref) and st.segments == ost.segments
+    # fast build: refused, not silently replaced
+    with pytest.raises(rtow.RtowError):
+        ctx.render(sc, rtow.make_config(*args, precision=rtow.F64_FAST, kernel=rtow.KERNEL_REFTREE))
+    exe = REPO / "raytracing-one-weekend_amd" / "rtweekend"
+    r = subprocess.run([str(exe), "-w", "90", "-a", "1.5", "-s", "6", "-t", "3", "-c", "12", "-n", "4", "-m", "--seed", "77",
+                        "--precision", "strict", "--kernel", "reftree"], capture_output=True, check=True)
+    cfg = rtow.make_config(90, 60, 6, 3, 12, seed=77)
+    ref, _ = orc.render(orc.OrcScene.cover(4, 1.5, True), cfg, orc.RNG_PHILOX, nthreads=4)
+    assert r.stdout == orc.ppm_text(ref, 90, 60, 6)
+    assert b"Total BVH stupid volume" in r.stderr
