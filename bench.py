@@ -101,6 +101,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N=1: skip the shortened runs of the other BASELINE configs")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-reference-boundary", action="store_true",
+                    help="N=1: skip the lines for nstreams = 4 (the reference's default thread count)")
     ap.add_argument("--precision", choices=["fast", "strict", "f32"], default="fast",
                     help="fast/strict: binary64 (the metric's arithmetic); f32: the preview build, never the headline")
     ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid", "bvh4"], default="auto")
@@ -140,13 +142,34 @@ def launch_ranks(a) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # poll ALL ranks: if any dies at start-up (device not visible, import error) the others would sit in
+    # init_process_group / barrier until torch's timeout; end them and fail now instead
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = []
+    while True:
+        rcs = [p.poll() for p in procs]
+        failed = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed or all(rc is not None for rc in rcs):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=20)
+    sys.stdout.write((out0[0] if out0 else b"").decode())
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write(f"bench.py: ranks failed: {bad}\n")
+    if failed:
+        sys.stderr.write(f"bench.py: ranks failed: {failed}\n")
         return 1
     return 0
 
@@ -225,6 +248,17 @@ KERNEL_NAMES = {1: "stream (every lane tests every primitive, scalar-load broadc
                 4: "bvh4 (per-lane ordered walk of a 4-wide BVH, stack in LDS; image or its top levels in LDS)"}
 
 
+def kernel_source_sha():
+    """sha1 over the trace kernel's sources: a committed PMC profile belongs to the kernel it was taken from."""
+    import hashlib
+
+    h = hashlib.sha1()
+    d = ROOT / "raytracing-one-weekend_amd" / "csrc"
+    for f in sorted(list(d.glob("rtow_trace_*.h")) + [d / "rtow_device.h"]):
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def load_pmc(workload, precision, kernel_used):
     """Derived PMC numbers of the committed profile of this workload/kernel (profiles/r02_pmc_*.json,
     written by scripts/pmc_summary.py from separate rocprofv3 --pmc passes), or None."""
@@ -238,7 +272,7 @@ def load_pmc(workload, precision, kernel_used):
         if not d or pj.get("workload") != workload or pj.get("precision") != precision or \
                 pj.get("kernel_used") != kernel_used:
             continue
-        best = dict(d, pmc_file=f"profiles/{f.name}")
+        best = dict(d, pmc_file=f"profiles/{f.name}", kernel_source_sha=pj.get("kernel_source_sha"))
     return best
 
 
@@ -250,11 +284,17 @@ def rooflines(scene, st, kernel_ms, rows, W, workload, precision):
     alg_bytes = math.ceil(seg / 64) * bytes_all + fb_bytes
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     pmc = load_pmc(workload, precision, st.kernel_used)
-    traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+    # counters of ANOTHER build of the kernel are not this kernel's: null, with the file named
+    pmc_stale = bool(pmc) and pmc.get("kernel_source_sha") != kernel_source_sha()
+    traffic = pmc.get("hbm_bytes_per_launch") if (pmc and not pmc_stale) else None
     roof = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "kernel": "rtow_trace_" + precision, "kernel_ms": round(kernel_ms, 4),
+        "binding_bound": "valu_issue (see roofline_valu): `achieved` here is the metric's equivalent-streaming figure, "
+                         "not bytes the kernel moves; measured_hbm_GBps is",
+        "traffic_source": None if not pmc else (pmc["pmc_file"] + (" (STALE: taken from another build of the kernel, "
+                                                                   "not reported)" if pmc_stale else "")),
         "algorithmic_bytes_per_launch": alg_bytes,
         "model": "EQUIVALENT STREAMING bandwidth, SURVEY.md §8d: ceil(segments/64) * sum(N_class * record bytes) "
                  "+ rows*W*24 B; f64 records: sphere 32 B, moving sphere 56 B, triangle 72 B.  Not the bytes the "
@@ -289,9 +329,10 @@ def rooflines(scene, st, kernel_ms, rows, W, workload, precision):
         "bound": "valu_issue", "achieved": round(tf, 3), "peak": F64_VALU_PEAK_TF, "unit": "TFLOP/s",
         "frac": round(tf / F64_VALU_PEAK_TF, 5),
         "model": "useful hit-test flops per second (counted by the kernel) vs the f64 vector peak; " + fmodel,
-        "issue_utilisation": pmc.get("valu_issue_utilisation") if pmc else None,
-        "lane_activity": pmc.get("lane_activity") if pmc else None,
+        "issue_utilisation": pmc.get("valu_issue_utilisation") if (pmc and not pmc_stale) else None,
+        "lane_activity": pmc.get("lane_activity") if (pmc and not pmc_stale) else None,
         "pmc_file": pmc.get("pmc_file") if pmc else None,
+        "pmc_stale": pmc_stale if pmc else None,
         "pmc_note": "issue_utilisation = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); lane_activity = "
                     "SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU*64); from separate rocprofv3 --pmc passes of this "
                     "workload (null: no committed profile matches this workload/kernel; the two counters come from "
@@ -385,9 +426,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=__import__("datetime").timedelta(seconds=180))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=__import__("datetime").timedelta(seconds=180))
 
     kind, W, aspect, spp0, DEPTH, spi, base_cfg = WORKLOADS[a.workload]
     H = rtow.image_height(W, aspect)
@@ -533,12 +574,49 @@ def main():
                 "value": round(W * H * spp_eff / e1 / 1e6, 3), "unit": "Msamples/s", "ms_per_call": round(e1 * 1e3, 4),
                 "calls": n_e2e, "upload_ms": round(bi.upload_ms, 3),
                 "build_ms": round(bi.bvh_build_ms + bi.grid_build_ms, 3),
-                "region": "rtow_render(): scene upload + acceleration build + trace + reduce + D2H of W*H*3 f64 sums "
-                          "into caller memory (SURVEY.md §8d; `value` at the top excludes upload and D2H)",
+                "region": "rtow_render(): scene upload + acceleration build (only what this config's kernel reads) + trace + "
+                          "reduce + D2H of W*H*3 f64 sums into caller memory (SURVEY.md §8d)",
                 "rgb8": {"value": round(W * H * spp_eff / e8 / 1e6, 3), "ms_per_call": round(e8 * 1e3, 4),
                          "region": "rtow_render_rgb8(): the same with write_color on the device and W*H*3 BYTES to the "
                                    "host — the values the reference prints into its PPM (src/render.cpp:11-20,182-186)"},
             }
+            # SURVEY §8d's timed region as a co-equal headline: `value` is the device-resident rate the contract
+            # asks for (inputs in HBM when the clock starts), `value_e2e` what one call of the boundary delivers
+            out["value_e2e"] = out["end_to_end"]["rgb8"]["value"]
+            out["ms_per_step_e2e"] = out["end_to_end"]["rgb8"]["ms_per_call"]
+            out["e2e_over_device_resident"] = round(out["value_e2e"] / value, 4)
+            ctx.upload(scene)  # (rtow_render uploads only what its kernel reads: the full scene again for what follows)
+        if world == 1 and a.workload == "cover" and not a.no_reference_boundary:
+            # What a drop-in caller of render(scene, cfg) gets: Config::nthreads = 4 (src/render.h:18) -> nstreams = 4,
+            # at the two sample counts of BASELINE configs[1] / [2], device-resident and through the boundary call
+            rb = {"nstreams": 4, "note": "the reference's default thread count; fast build: the work items follow the "
+                                         "sample schedule whatever nstreams is (include/rtow.h, rtow_debug_schedule)"}
+            import numpy as np
+
+            import ctypes as C3
+
+            host8b = np.zeros((H, W, 3), dtype=np.uint8)
+            Lb = rtow.lib()
+            Lb.rtow_render_rgb8.argtypes = [C3.c_void_p, C3.POINTER(rtow.Scene), C3.POINTER(rtow.Config), C3.c_void_p,
+                                            C3.POINTER(rtow.Stats)]
+            for spp_rb, nsteps in ((100, 5), (500, 2)):
+                cfg4 = rtow.make_config(W, H, spp_rb, 4, DEPTH, seed=SEED, precision=precision, kernel=kernel)
+                ms4, kms4, _ = timed_render_loop(ctx, cfg4, local.data_ptr(), stream.cuda_stream, dev, nsteps, 1)
+
+                def one():
+                    rtow.check(Lb.rtow_render_rgb8(ctx._h, C3.byref(scene.c), C3.byref(cfg4),
+                                                   host8b.ctypes.data_as(C3.c_void_p), None), "rtow_render_rgb8")
+
+                one()
+                tb = time.perf_counter()
+                for _ in range(nsteps):
+                    one()
+                eb = (time.perf_counter() - tb) / nsteps
+                ctx.upload(scene)
+                rb[f"spp{spp_rb}"] = {"value": round(W * H * spp_rb / (ms4 * 1e-3) / 1e6, 3), "ms_per_step": round(ms4, 4),
+                                      "kernel_ms": round(kms4, 4), "samples_per_item_strict_would_be": spp_rb // 4,
+                                      "value_e2e_rgb8": round(W * H * spp_rb / eb / 1e6, 3), "ms_per_call_e2e": round(eb * 1e3, 4)}
+            out["reference_boundary"] = rb
         if world == 1 and a.workload == "cover" and spp == 100 and not a.no_scaling_base:
             # like-for-like base of the N>1 lines (configs[2], 500 spp): the same frame on this one
             # GPU, measured after the timed region (a longer launch amortises the end-of-launch tail)

@@ -129,12 +129,31 @@ rtow::FastDiv make_fastdiv(uint32_t d) {
   return f;
 }
 
+// Host-to-device copies of a scene upload go through one pinned staging arena and are queued on the null
+// stream without a host wait each (a dozen small synchronous copies were 0.2 ms of a cover-scene upload); the
+// arena is rewound at the start of the next upload, behind that upload's device synchronisation.  What does
+// not fit (a big mesh's images) is copied synchronously from pageable memory as before.
+struct PinnedArena {
+  unsigned char *p = nullptr;
+  size_t cap = 0, used = 0;
+};
+thread_local PinnedArena *g_arena = nullptr;  // the arena of the upload in progress on this thread
+
 template <class T>
 int upload(DevBuf &b, const std::vector<T> &v) {
   size_t n = v.size() * sizeof(T);
   int rc = b.ensure(n ? n : sizeof(T));
   if (rc) return rc;
-  if (n) HIPCHK(hipMemcpy(b.p, v.data(), n, hipMemcpyHostToDevice));
+  if (!n) return RTOW_OK;
+  PinnedArena *a = g_arena;
+  const size_t at = a ? (a->used + 255) / 256 * 256 : 0;
+  if (a && a->p && at + n <= a->cap) {
+    std::memcpy(a->p + at, v.data(), n);
+    a->used = at + n;
+    HIPCHK(hipMemcpyAsync(b.p, a->p + at, n, hipMemcpyHostToDevice, nullptr));
+  } else {
+    HIPCHK(hipMemcpy(b.p, v.data(), n, hipMemcpyHostToDevice));
+  }
   return RTOW_OK;
 }
 
@@ -238,8 +257,13 @@ struct Knobs {
                                   //   (default 8), else the entries per lane beside the staged top of the tree (default 24)
   int sched_chunk = 16;           // RTOW_SCHED_CHUNK: fast builds: samples per work item in the bulk of a launch (0 = no
                                   //   schedule: one item per stream and pixel, like the strict build)
-  double sched_ratio = 1.3;       // RTOW_SCHED_RATIO: a level of the shrinking end of the schedule is at most 1/ratio of
-                                  //   all the samples that come after it
+  double sched_ratio = 0.0;       // RTOW_SCHED_RATIO: > 0: the schedule ends on levels that shrink to single samples, each at
+                                  //   most 1/ratio of all the samples behind it, queue level-major (measured: worse than
+                                  //   exporting, the last level revisits the costly pixels right before the end); 0 = plain chunks
+  double budget_segs = 2.5;       // RTOW_BUDGET_SEGS: segments per sample assumed by the segment budget of an item
+  double budget_factor = 0.5;     // RTOW_BUDGET_FACTOR: the budget as a share of the time the queue still lasts
+  bool budget_off = false;        // RTOW_NO_EXPORT: items never export samples
+  int ovf_cap = 16384;            // RTOW_OVF_CAP: ring entries per workgroup
   void read() {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
     auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
@@ -281,9 +305,17 @@ struct Knobs {
     }
     bvh4_stack_k = std::min(std::max(geti("RTOW_BVH4_STACK_K", 0), 0), 64);
     sched_chunk = std::min(std::max(geti("RTOW_SCHED_CHUNK", 16), 0), 4096);
-    sched_ratio = std::min(std::max(getd("RTOW_SCHED_RATIO", 1.3), 1.0), 16.0);
+    sched_ratio = std::min(std::max(getd("RTOW_SCHED_RATIO", 0.0), 0.0), 16.0);
+    budget_segs = std::min(std::max(getd("RTOW_BUDGET_SEGS", 2.5), 0.01), 1000.0);
+    budget_factor = std::min(std::max(getd("RTOW_BUDGET_FACTOR", 0.5), 0.0), 100.0);
+    budget_off = std::getenv("RTOW_NO_EXPORT") != nullptr;
+    ovf_cap = std::min(std::max(geti("RTOW_OVF_CAP", 16384), 64), 1 << 20);
   }
 };
+
+// what a scene upload builds besides the record arrays: rtow_scene_upload builds everything (the scene stays
+// resident for any later render); rtow_render / rtow_render_rgb8 know their config and build what its kernel reads
+constexpr unsigned kNeedBvh = 1u, kNeedGrid = 2u, kNeedF32 = 4u, kNeedAll = 7u;
 
 struct rtow_ctx {
   int device = 0;
@@ -316,8 +348,12 @@ struct rtow_ctx {
   } host_scene;
   DevBuf rtree;
   bool have_rtree = false;
+  PinnedArena arena;     // staging of the scene uploads
+  unsigned built = 0;    // kNeed* bits of what the resident scene holds (rtow_render uploads only what its kernel reads)
   // workspace
   DevBuf partials, stack, counters, spill;
+  DevBuf ovf_desc, ovf_color;  // rings of exported samples (one per workgroup), see rtow_trace_body.h
+  uint32_t launch_serial = 0;  // tag of the ring entries of a launch (entries of earlier launches are stale, never cleared)
   DevBuf out, out8;  // rtow_render / rtow_render_rgb8: device-side output of the host-buffer entry points
   // level table of the last render ([level][first sample, count], see make_schedule): device copy, pinned
   // staging buffer, and the key it was built for
@@ -380,9 +416,10 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
-                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->lvl_dev, &c->rtree})
+                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->lvl_dev, &c->rtree, &c->ovf_desc, &c->ovf_color})
     b->release();
   if (c->lvl_pinned) (void)hipHostFree(c->lvl_pinned);
+  if (c->arena.p) (void)hipHostFree(c->arena.p);
   for (int i = 0; i < kEventRing; ++i)
     for (int k = 0; k < 2; ++k)
       if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
@@ -420,12 +457,28 @@ static int validate_scene(const rtow_scene_t *s) {
   return RTOW_OK;
 }
 
-static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
+static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need);
+static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) { return scene_upload(c, s, kNeedAll); }
+
+static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
   if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
   int rc = validate_scene(s);
   if (rc) return rc;
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipDeviceSynchronize());
+  if (!c->arena.p) {
+    if (hipHostMalloc((void **)&c->arena.p, 8u << 20, hipHostMallocDefault) == hipSuccess)
+      c->arena.cap = 8u << 20;
+    else
+      c->arena.p = nullptr;  // (uploads then copy synchronously)
+  }
+  c->arena.used = 0;
+  struct ArenaScope {  // the free function upload() finds the arena of the upload in progress here
+    explicit ArenaScope(PinnedArena *a) { g_arena = a; }
+    ~ArenaScope() { g_arena = nullptr; }
+  } arena_scope(&c->arena);
+  if (need & kNeedF32) need |= kNeedBvh | kNeedGrid;  // the binary32 images are derived from the binary64 ones
+  c->built = 0;
   c->have_scene = false;
   c->have_rtree = false;
   c->build_info.ref_tree_nodes = 0;
@@ -537,6 +590,7 @@ static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   c->have_bvh4 = false;
   c->build_info.bvh4_nodes = 0;
   c->build_info.bvh4_image_bytes = 0;
+  if (need & kNeedBvh) {
   if (c->builder == RTOW_BUILDER_DEVICE_LBVH) {
     // the tree is built in HBM from the record arrays just uploaded; the host only lays out
     // the image sections around it
@@ -608,6 +662,7 @@ static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
       }
     }
   }
+  }  // kNeedBvh
   const double t_bvh1 = now_ms();
   c->blob_bytes = (uint32_t)img.total_bytes;
   c->bvh_nodes = img.n_nodes;
@@ -619,7 +674,9 @@ static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
   // skip the host build, a GRID request then falls back to the BVH
   const int grid_max_tris = c->knobs.grid_max_tris;
   bool grid_on_device = false;
-  if (nt <= grid_max_tris && c->builder == RTOW_BUILDER_DEVICE_LBVH) {
+  if (!(need & kNeedGrid)) {
+    // (not asked for)
+  } else if (nt <= grid_max_tris && c->builder == RTOW_BUILDER_DEVICE_LBVH) {
     // the same grid, built in HBM (csrc/rtow_build_grid.hip); the host does the scalar steps between
     // the phases with the code the host builder uses, so the image is byte-identical
     grid_on_device = true;
@@ -723,7 +780,8 @@ static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     if ((rc = upload(c->cam_dev, one))) return rc;
   }
   // ---- the f32 build's images (same trees, binary32 records for the small primitives) ----
-  {
+  c->ds32 = c->ds;
+  if (need & kNeedF32) {
     Image32 b32;
     const bool device_tree = c->builder == RTOW_BUILDER_DEVICE_LBVH;
     make_image32(device_tree ? nullptr : img.blob.data(), img.off_sph, sph, mov, leaf_direct ? tri_img : tri,
@@ -765,6 +823,7 @@ static int impl_scene_upload(rtow_ctx *c, const rtow_scene_t *s) {
     for (int i = 0; i < 21; ++i) cam32[i] = (float)cd[i];
     if ((rc = upload(c->cam32_dev, cam32))) return rc;
   }
+  c->built = need;
   c->have_scene = true;
   rtow_build_info_t &bi = c->build_info;
   bi.builder = c->builder;
@@ -847,7 +906,7 @@ int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t cap
 static void make_schedule(uint32_t first, uint32_t total, uint32_t chunk, double ratio, std::vector<uint32_t> &out) {
   std::vector<uint32_t> tail;  // in reverse order of execution
   uint32_t sum = 0;
-  while (sum < total) {
+  while (ratio > 0.0 && sum < total) {
     uint32_t n = (uint32_t)((double)sum / ratio);
     n = std::max(n, 1u);
     n = std::min(n, chunk);
@@ -956,7 +1015,7 @@ static int impl_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb
   // level sums in level order either way).
   unsigned long long max_levels = (unsigned long long)n_levels;
   if (npix > 0) {
-    max_levels = c->knobs.partials_cap / (npix * 24ull);
+    max_levels = c->knobs.partials_cap / (npix * 32ull);
     if (0xfff00000ULL / npix < max_levels) max_levels = 0xfff00000ULL / npix;  // 32-bit item index
     if (max_levels < 1) max_levels = 1;
   }
@@ -1018,6 +1077,9 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
              : bvh4_ok ? RTOW_KERNEL_BVH4 : RTOW_KERNEL_BVH;
   if (kernel == RTOW_KERNEL_GRID && !c->have_grid) kernel = RTOW_KERNEL_BVH;  // scene not suited to a grid
   if (kernel == RTOW_KERNEL_BVH4 && !bvh4_ok) kernel = RTOW_KERNEL_BVH;
+  if (((kernel == RTOW_KERNEL_BVH || kernel == RTOW_KERNEL_BVH4) && !(c->built & kNeedBvh)) || (f32 && !(c->built & kNeedF32)))
+    return fail(RTOW_ENOSCENE, "the resident scene was uploaded by rtow_render for another kernel / precision: "
+                               "call rtow_scene_upload before rtow_render_device");
   if (kernel == RTOW_KERNEL_REFTREE) {
     // the reference's own tree and box test: an exactness mode, so it exists in the strict build only
     if (!strict) return fail(RTOW_EINVAL, "RTOW_KERNEL_REFTREE needs precision RTOW_F64_STRICT");
@@ -1128,7 +1190,15 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   const unsigned long long n_lanes = (unsigned long long)grid * block;
 
   const size_t depth_slots = (size_t)(cfg->max_child_rays > 0 ? cfg->max_child_rays : 1);
-  if ((rc = c->partials.ensure((size_t)n_items * 3 * sizeof(double))) ||
+  const uint32_t ovf_cap = (uint32_t)c->knobs.ovf_cap;
+  {
+    // ring descriptors carry the tag of the launch that wrote them (never 0): fresh memory must not look tagged
+    const void *before = c->ovf_desc.p;
+    if ((rc = c->ovf_desc.ensure((size_t)grid * ovf_cap * 4 * sizeof(uint32_t)))) return rc;
+    if (c->ovf_desc.p != before) HIPCHK(hipMemsetAsync(c->ovf_desc.p, 0, c->ovf_desc.bytes, st));
+  }
+  if ((rc = c->partials.ensure((size_t)n_items * 4 * sizeof(double))) ||
+      (rc = c->ovf_color.ensure((size_t)grid * ovf_cap * 3 * sizeof(double))) ||
       (rc = c->stack.ensure(strict ? depth_slots * (size_t)n_lanes * sizeof(uint32_t) : 4)) ||  // strict build only
       (rc = c->counters.ensure(48 * sizeof(unsigned long long))))
     return rc;
@@ -1146,13 +1216,15 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   P.H = cfg->image_height;
   P.spt = spt;
   P.nstreams = streams_now;
-  P.level_major = scheduled ? 1u : 0u;
+  P.level_major = scheduled && c->knobs.sched_ratio > 0.0 ? 1u : 0u;
   P.lvl = (const uint32_t *)c->lvl_dev.p + 2 * (size_t)lvl_first;
-  {
-    // the work a workgroup may still be holding when the queue runs dry: about 1024 samples (one per lane)
-    const uint32_t last = std::max<uint32_t>(c->lvl_host[2 * (size_t)(lvl_first + lvl_count - 1) + 1], 1u);
-    P.wg_batch_floor = std::min<uint32_t>(std::max<uint32_t>(1024u / last, 64u), 1024u);
-  }
+  // exported samples: one ring per workgroup; an item's segment budget is the number of trips the queue still
+  // lasts when it is fetched — items left * samples per item * segments per sample / lanes — times a factor
+  P.ovf_desc = (uint32_t *)c->ovf_desc.p;
+  P.ovf_color = (double *)c->ovf_color.p;
+  P.ovf_cap = ovf_cap;
+  P.ovf_tag = ++c->launch_serial ? c->launch_serial : ++c->launch_serial;  // (never 0)
+  P.budget_k = c->knobs.budget_off ? 1e30f : (float)(c->knobs.budget_segs * c->knobs.budget_factor / (double)n_lanes);
   P.max_child_rays = cfg->max_child_rays;
   P.rank = cfg->rank;
   P.nranks = cfg->nranks;
@@ -1238,6 +1310,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   }
   rtow::ReduceParams R;
   R.partials = P.partials;
+  R.ovf_color = P.ovf_color;
   R.out = (double *)d_rgb_sums;
   R.npix3 = (uint32_t)(npix * 3);
   R.nstreams = streams_now;
@@ -1341,16 +1414,40 @@ int rtow_profile_collect(rtow_ctx *c, double *kernel_ms_sum, int32_t *launches) 
   return RTOW_OK;
 }
 
+// Upload for ONE render whose config is known: only what its kernel reads (the cover scene through the grid
+// kernel needs no BVH image, no 4-wide image and no binary32 images: 0.48 -> 0.15 ms per call).
+static int upload_for(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  int rc = validate_scene(scene);
+  if (rc) return rc;
+  const long long np = (long long)scene->n_spheres + scene->n_moving + scene->n_triangles;
+  unsigned need;
+  const int k = cfg->kernel;
+  if (cfg->precision == RTOW_F32)
+    need = kNeedAll;
+  else if (k == RTOW_KERNEL_REFTREE || k == RTOW_KERNEL_BRUTE || (k == RTOW_KERNEL_AUTO && np <= 16))
+    need = 0u;
+  else if ((k == RTOW_KERNEL_AUTO || k == RTOW_KERNEL_GRID) && scene->n_triangles == 0)
+    need = kNeedGrid;
+  else if (k == RTOW_KERNEL_GRID)
+    need = kNeedGrid | kNeedBvh;
+  else
+    need = kNeedBvh;
+  rc = scene_upload(c, scene, need);
+  if (rc == RTOW_OK && (need & kNeedGrid) && !(need & kNeedBvh) && !c->have_grid)
+    rc = scene_upload(c, scene, need | kNeedBvh);  // the scene does not suit a grid: the walk falls back to the BVH
+  return rc;
+}
+
 static int impl_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t *cfg, double *rgb_sums_host,
                 rtow_stats_t *stats) {
   if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
   if (!rgb_sums_host) return fail(RTOW_EINVAL, "rgb_sums_host is NULL");
   int rc = validate_cfg(cfg);
   if (rc) return rc;
-  if ((rc = rtow_scene_upload(c, scene))) return rc;
+  if ((rc = upload_for(c, scene, cfg))) return rc;
   const int rows = rtow_local_rows(cfg);
   const size_t bytes = (size_t)rows * cfg->image_width * 3 * sizeof(double);
-  rtow_stats_t local;
   if (bytes == 0) {
     if (stats) {
       std::memset(stats, 0, sizeof *stats);
@@ -1361,7 +1458,7 @@ static int impl_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config
   void *d_out = c->out.p;
   if (cfg->accumulate)  // continue from the caller's sums
     HIPCHK(hipMemcpy(d_out, rgb_sums_host, bytes, hipMemcpyHostToDevice));
-  rc = rtow_render_device(c, cfg, d_out, nullptr, stats ? stats : &local);
+  rc = rtow_render_device(c, cfg, d_out, nullptr, stats);  // (no stats: no host wait before the copy below)
   if (rc == RTOW_OK) HIPCHK(hipMemcpy(rgb_sums_host, d_out, bytes, hipMemcpyDeviceToHost));
   return rc;
 }
@@ -1377,16 +1474,15 @@ static int impl_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_c
   const int spp_eff = cfg->samples_per_pixel / cfg->nstreams * cfg->nstreams;  // src/render.cpp:185
   if (spp_eff <= 0) return fail(RTOW_EINVAL, "no effective samples (samples_per_pixel < nstreams)");
   if (cfg->accumulate) return fail(RTOW_EINVAL, "rtow_render_rgb8 owns its sums: accumulate must be 0");
-  if ((rc = rtow_scene_upload(c, scene))) return rc;
+  if ((rc = upload_for(c, scene, cfg))) return rc;
   const int rows = rtow_local_rows(cfg);
   const size_t n = (size_t)rows * cfg->image_width * 3;
-  rtow_stats_t local;
   if (n == 0) {
     if (stats) std::memset(stats, 0, sizeof *stats);
     return RTOW_OK;
   }
   if ((rc = c->out.ensure(n * sizeof(double))) || (rc = c->out8.ensure(n))) return rc;  // kept across calls
-  rc = rtow_render_device(c, cfg, c->out.p, nullptr, stats ? stats : &local);
+  rc = rtow_render_device(c, cfg, c->out.p, nullptr, stats);
   if (rc == RTOW_OK) rc = rtow_tonemap_device(c, c->out.p, (int64_t)n, spp_eff, c->out8.p, nullptr);
   if (rc == RTOW_OK) HIPCHK(hipMemcpy(rgb8_host, c->out8.p, n, hipMemcpyDeviceToHost));
   return rc;

@@ -102,7 +102,11 @@ struct TraceParams {
   FastDiv div_ns;                     // tiled order: (item / 64) -> (tile, level)
   FastDiv div_ntiles;                 // level-major order: (item / 64) -> (level, tile)
   uint32_t n_tiles;                   // 64-pixel tiles of this rank's rows
-  uint32_t wg_batch_floor; // smallest batch a workgroup takes from the global queue as the queue drains (items)
+  // exported samples (rtow_trace_body.h): one ring of `ovf_cap` entries per workgroup
+  uint32_t *ovf_desc;      // [grid][ovf_cap][4]  pixel, sample, tag of the launch, -
+  double *ovf_color;       // [grid][ovf_cap][3]  colour of the exported sample
+  uint32_t ovf_cap, ovf_tag;
+  float budget_k;          // segment budget of an item = items left in the queue * its samples * budget_k
   const uint32_t *lvl;     // [nstreams][2]  first sample index, sample count of each level (device memory, scalar loads)
   // pixel order inside this rank's rows: tiles of 2^tile_w_log2 x 2^tile_h_log2 = 64 pixels,
   // tiles row-major (tile_h_log2 == 0 and tile_w_log2 == 0: plain row-major order)
@@ -110,7 +114,7 @@ struct TraceParams {
   FastDiv div_tpr;         // tiles per row = W >> tile_w_log2
   uint32_t div_tpr_n;      // the divisor itself
   uint32_t n_tile_rows, sky_rows;  // tiled order: tile rows of this rank, and how many of the top ones come last
-  double *partials;        // [level][local_rows*W][3]
+  double *partials;        // [level][local_rows*W][4]  colour sums + (ring slot << 32 | count) of the item's exported samples
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   uint32_t *spill;         // BVH4 kernel: traversal stack entries beyond the LDS part, [entry][n_lanes]
   uint32_t b4_trips;       // BVH4: 1 = the trip-structured kernel (rtow_trace_body.h, default), 0 = the state machine
@@ -123,7 +127,8 @@ struct TraceParams {
 };
 
 struct ReduceParams {
-  const double *partials;  // [stream][tiled pixel][3]
+  const double *partials;  // [level][tiled pixel][4]: r g b sums, exported samples (ring slot << 32 | count)
+  const double *ovf_color; // colours of the exported samples, by ring slot
   double *out;             // [local_rows*W][3], row-major
   uint32_t npix3;          // local_rows*W*3
   int32_t nstreams;

@@ -71,8 +71,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
   Rng g = {0, 0, 0};
   uint32_t nseg = 0, nnode = 0, nprim = 0;
   ItemPool pool;
-  const uint32_t n_wgs = gridDim.x;
-  Stamps<STAMPS> stamps;
+    Stamps<STAMPS> stamps;
   stamps.start();
   if constexpr (STAMPS) {
     if (lane == 0) atomicMin(P.t_origin, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -123,14 +122,15 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
         if (need_mask != 0ull) {
           const RTOW_CONST TraceParams *kp = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
           asm volatile("" : "+s"(kp));  // opaque per trip: keeps the loads from being hoisted out of the loop
-          if (need_item && item != 0xffffffffu) {
-            double *dst = P.partials + (size_t)item * 3;
+          if (need_item && item != 0xffffffffu) {  // (records of 4 doubles: the 4th says "no exported samples")
+            double *dst = P.partials + (size_t)item * 4;
             dst[0] = acc.x;
             dst[1] = acc.y;
             dst[2] = acc.z;
+            dst[3] = 0.0;
           }
-          const unsigned long long mine = take_items(pool, need_mask, lane, n_wgs, kp, P.counters);
-          if (need_item && mine != kNoItemNow) {
+          const unsigned long long mine = take_items(pool, need_mask, lane, kp, P.counters);
+          if (need_item) {
             if (mine >= (unsigned long long)kp->n_items) {
               phase = PH_DEAD;
               item = 0xffffffffu;

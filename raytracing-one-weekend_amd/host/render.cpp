@@ -327,9 +327,14 @@ static void render_flat(FlatScene *flat, const Config &cfg) {
   if (bi.ref_tree_nodes > 0)  // --kernel reftree: the reference's own tree and its diagnostic (src/render.cpp:148)
     std::cerr << "Total BVH stupid volume: " << bi.ref_tree_stupid_volume << "\n"
               << "Reference tree: " << bi.ref_tree_nodes << " nodes, built in " << bi.ref_tree_build_ms << " ms\n";
-  std::cerr << "BVH image: " << bi.bvh_nodes << " nodes, " << bi.bvh_image_bytes << " bytes, built on the "
-            << (bi.builder == RTOW_BUILDER_DEVICE_LBVH ? "device (LBVH)" : "host (SAH)") << " in " << bi.bvh_build_ms
-            << " ms\n";
+  // what the device walked (the reference prints its tree's diagnostic here, src/render.cpp:148; only the
+  // structures this render's kernel reads are built)
+  if (bi.bvh_image_bytes > 0)
+    std::cerr << "BVH image: " << bi.bvh_nodes << " nodes, " << bi.bvh_image_bytes << " bytes, built on the "
+              << (bi.builder == RTOW_BUILDER_DEVICE_LBVH ? "device (LBVH)" : "host (SAH)") << " in " << bi.bvh_build_ms
+              << " ms" << (bi.bvh4_nodes > 0 ? "; 4-wide image: " + std::to_string(bi.bvh4_nodes) + " nodes" : std::string()) << "\n";
+  if (bi.grid_image_bytes > 0)
+    std::cerr << "Grid image: " << bi.grid_image_bytes << " bytes, built in " << bi.grid_build_ms << " ms\n";
   std::cerr << "Traced " << st.samples << " samples, " << st.segments << " ray segments; kernel "
             << st.kernel_ms << " ms ("
             << (st.kernel_ms > 0 ? st.samples / st.kernel_ms / 1e3 : 0.0) << " Msamples/s)\n";

@@ -6,7 +6,7 @@
 export TMPDIR=/tmp
 TAG=${1:-x}; shift
 BENCH_ARGS="$*"
-run() { name=$1; shift; timeout -k 5 90 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${TAG}_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scaling-base --no-other-configs --no-end-to-end $BENCH_ARGS > gpurun_out/pmc_${TAG}_$name.log 2>&1 || { echo "pmc $name failed"; grep -m1 "error code" gpurun_out/pmc_${TAG}_$name.log; return 1; }; echo "pass $name ok"; }
+run() { name=$1; shift; timeout -k 5 90 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${TAG}_$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scaling-base --no-other-configs --no-end-to-end --no-reference-boundary $BENCH_ARGS > gpurun_out/pmc_${TAG}_$name.log 2>&1 || { echo "pmc $name failed"; grep -m1 "error code" gpurun_out/pmc_${TAG}_$name.log; return 1; }; echo "pass $name ok"; }
 run ta1 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum &&
 run ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum &&
 run tcp1 TCP_GATE_EN1_sum TCP_GATE_EN2_sum &&

@@ -48,4 +48,11 @@ if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
 if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_INST_ANY") is not None:
     d["wave_wait_inst_frac"] = round(g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), 4)
 out["derived"] = d
+# which kernel these counters belong to: bench.py reports them only for the same sources
+import hashlib, pathlib
+_h = hashlib.sha1()
+_d = pathlib.Path(__file__).resolve().parent.parent / "raytracing-one-weekend_amd" / "csrc"
+for _f in sorted(list(_d.glob("rtow_trace_*.h")) + [_d / "rtow_device.h"]):
+    _h.update(_f.read_bytes())
+out["kernel_source_sha"] = _h.hexdigest()[:16]
 print(json.dumps(out, indent=1))

@@ -395,10 +395,16 @@ def test_repeatable_and_independent_of_stream_count_in_expectation(ctx):
     a, _ = ctx.render(scene, cfg)
     b, _ = ctx.render(scene, cfg)
     assert np.array_equal(a, b)  # dynamic work distribution must not leak into the image
-    # same samples, different summation tree: equal to rounding only
+    # same samples through another stream count.  Fast build: the same work items (a schedule over the sample
+    # range, independent of nstreams), the same image.  Strict build: one item per stream like the reference's
+    # threads, i.e. another summation tree: equal to rounding only
     cfg1 = rtow.make_config(48, 32, 12, 1, 50, seed=8, precision=rtow.F64_FAST)
     c, _ = ctx.render(scene, cfg1)
-    assert np.allclose(a, c, rtol=1e-12, atol=1e-12) and not np.array_equal(a, c)
+    assert np.array_equal(a, c)
+    s3, _ = ctx.render(scene, rtow.make_config(48, 32, 12, 3, 50, seed=8, precision=rtow.F64_STRICT))
+    s1, _ = ctx.render(scene, rtow.make_config(48, 32, 12, 1, 50, seed=8, precision=rtow.F64_STRICT))
+    assert np.allclose(s3, s1, rtol=1e-12, atol=1e-12) and not np.array_equal(s3, s1)
+    assert np.allclose(a, s1, rtol=1e-9, atol=1e-9)
     # another seed: a different image
     cfg2 = rtow.make_config(48, 32, 12, 3, 50, seed=9, precision=rtow.F64_FAST)
     d, _ = ctx.render(scene, cfg2)
@@ -560,6 +566,31 @@ def test_rtweekend_gpus_flag_partitions_like_one_device(ctx):
     assert bad.returncode != 0
 
 
+def _fast_default_image(scene, cfg, _cache={}):
+    """Fast-build image of (scene, cfg) from a context created WITHOUT any knob in the environment."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    key = (scene.c.n_prims, cfg.image_width, cfg.image_height, cfg.samples_per_pixel)
+    if key not in _cache:
+        env = {k: v for k, v in os.environ.items() if not k.startswith("RTOW_")}
+        with tempfile.TemporaryDirectory() as td:
+            code = (
+                "import sys, numpy as np; sys.path[:0] = %r\n"
+                "import rtow\n"
+                "scene = rtow.HostScene.cover(11, 1.5, True) if %d < 900 else rtow.HostScene.obj(%r, 16 / 9)\n"
+                "cfg = rtow.make_config(%d, %d, %d, 2, %d, seed=5, precision=rtow.F64_FAST)\n"
+                "img, st = rtow.Context(0).render(scene, cfg)\n"
+                "np.save(%r, img); open(%r, 'w').write(str(st.segments))\n"
+            ) % ([p for p in sys.path if p], scene.c.n_prims, str(GOLDEN / "suzanne.obj"), cfg.image_width, cfg.image_height,
+                 cfg.samples_per_pixel, cfg.max_child_rays, td + "/i.npy", td + "/s.txt")
+            subprocess.run([sys.executable, "-c", code], check=True, env=env, capture_output=True)
+            _cache[key] = (np.load(td + "/i.npy"), int(open(td + "/s.txt").read()))
+    return _cache[key]
+
+
 @pytest.mark.parametrize("env", [
     {"RTOW_WALK_CAP": "off", "RTOW_LEAF_VOTES": "1", "RTOW_FETCH_VOTES": "1"},   # every scheduling measure off
     {"RTOW_WALK_CAP": "1,64", "RTOW_LEAF_VOTES": "64", "RTOW_FETCH_VOTES": "64"},  # ... at its extreme (the grid's cap is clamped to 3)
@@ -567,11 +598,16 @@ def test_rtweekend_gpus_flag_partitions_like_one_device(ctx):
     {"RTOW_BVH4_SM": "1", "RTOW_SM4_VOTES": "64,64,64"},
     {"RTOW_BVH4_STACK_K": "2"},                                                      # nearly everything spills
     {"RTOW_NO_BVH4": "1"},                                                           # meshes on the binary walk
-], ids=["plain", "extreme", "sm4", "sm4-64", "spill", "bvh2"])
+    {"RTOW_BUDGET_FACTOR": "0"},                                                     # every item exports all but its first sample
+    {"RTOW_BUDGET_FACTOR": "0", "RTOW_OVF_CAP": "64"},                               # ... into rings that are full at once
+    {"RTOW_NO_EXPORT": "1"},                                                         # no item ever exports
+    {"RTOW_BUDGET_FACTOR": "0.02"},                                                  # exports from the middle of most items
+], ids=["plain", "extreme", "sm4", "sm4-64", "spill", "bvh2", "export-all", "export-full-ring", "no-export", "export-mid"])
 def test_scheduling_knobs_do_not_change_the_image(monkeypatch, env):
-    """Resumable walks, leaf / fetch quorums, the state-machine form of the BVH4 kernel and the size of the
-    LDS stack only decide WHEN a lane does its work: with any setting the strict image is the oracle's, bit
-    for bit, on the sphere scene (GRID) and on the mesh (BVH4).  (Knobs are read when a context is created.)"""
+    """Resumable walks, leaf / fetch quorums, the state-machine form of the BVH4 kernel, the size of the
+    LDS stack and the exporting of an item's last samples to other lanes (segment budget, ring size) only decide
+    WHEN and WHERE a sample is traced: with any setting the strict image is the oracle's, bit for bit, on the
+    sphere scene (GRID) and on the mesh (BVH4).  (Knobs are read when a context is created.)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     c = rtow.Context(0)
@@ -583,6 +619,11 @@ def test_scheduling_knobs_do_not_change_the_image(monkeypatch, env):
             img, st = c.render(scene, cfg)
             ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=16, accel=True)
             assert st.segments == ost.segments and np.array_equal(img, ref), (env, int((img != ref).sum()))
+            # the fast build (its own summation schedule) under the same setting: the image of the default setting
+            fcfg = rtow.make_config(cfg.image_width, cfg.image_height, 24, 2, cfg.max_child_rays, seed=5, precision=rtow.F64_FAST)
+            fimg, fst = c.render(scene, fcfg)
+            want = _fast_default_image(scene, fcfg)
+            assert np.array_equal(fimg, want[0]) and fst.segments == want[1], env
     finally:
         c.close()
 
@@ -703,7 +744,7 @@ def test_fast_build_image_does_not_depend_on_nstreams(ctx):
         pairs = (C.c_uint32 * 128)()
         n = rtow.lib().rtow_debug_schedule(ctx._h, C.byref(cfg), pairs, 64)
         sched = [(pairs[2 * i], pairs[2 * i + 1]) for i in range(n)]
-        assert sum(c for _, c in sched) == 48 and sched[0][0] == 0 and sched[-1][1] == 1
+        assert sum(c for _, c in sched) == 48 and sched[0][0] == 0
         assert all(a + c == b for (a, c), (b, _) in zip(sched, sched[1:]))  # contiguous sample ranges
         assert max(c for _, c in sched) <= 16
     assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])

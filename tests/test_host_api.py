@@ -206,10 +206,16 @@ def _schedule(cfg):
 @pytest.mark.parametrize("spp,ns", [(100, 10), (100, 4), (500, 4), (7, 3), (1, 1), (16, 1), (1024, 64)])
 def test_fast_build_schedule_properties(spp, ns, monkeypatch):
     """The levels a fast-build render is cut into (pure host arithmetic): they tile the effective sample
-    range, do not depend on nstreams beyond the effective spp, are at most RTOW_SCHED_CHUNK long, end on a
-    single sample, and from the shrinking part on no level is longer than the work queued behind it."""
-    for k in ("RTOW_SCHED_CHUNK", "RTOW_SCHED_RATIO"):
-        monkeypatch.delenv(k, raising=False)
+    range, do not depend on nstreams beyond the effective spp and are at most RTOW_SCHED_CHUNK long; with
+    RTOW_SCHED_RATIO (an experiment: shrinking levels, level-major queue) they end on a single sample and from
+    the shrinking part on no level is longer than the work queued behind it."""
+    monkeypatch.delenv("RTOW_SCHED_CHUNK", raising=False)
+    monkeypatch.delenv("RTOW_SCHED_RATIO", raising=False)
+    plain = _schedule(rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST))
+    assert plain[0][0] == 0 and sum(c for _, c in plain) == spp // ns * ns
+    assert all(a + c == b for (a, c), (b, _) in zip(plain, plain[1:])) and all(1 <= c <= 16 for _, c in plain)
+    assert all(c == 16 for _, c in plain[1:])  # chunks; the first one takes the remainder
+    monkeypatch.setenv("RTOW_SCHED_RATIO", "1.3")
     eff = spp // ns * ns
     cfg = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST)
     s = _schedule(cfg)
