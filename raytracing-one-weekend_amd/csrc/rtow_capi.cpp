@@ -78,7 +78,7 @@ namespace {
 
 constexpr int kBlock = 256;      // STREAM kernel workgroup
 constexpr int kBvhBlock = 512;   // BVH kernel workgroup (one LDS scene image per workgroup)
-constexpr unsigned kLdsLimit = 160u * 1024u - 64u;  // (64 B: the kernels' static LDS, the workgroup item pool)
+constexpr unsigned kLdsLimit = 160u * 1024u;
 constexpr int kEventRing = 256;
 
 struct DevBuf {
@@ -255,15 +255,8 @@ struct Knobs {
   int sm4_votes[3] = {8, 16, 16};  // RTOW_SM4_VOTES=restart,scatter,leaf: quorum of the state machine's blocks
   int bvh4_stack_k = 0;           // RTOW_BVH4_STACK_K: image staged whole if this many stack entries per lane still fit
                                   //   (default 8), else the entries per lane beside the staged top of the tree (default 24)
-  int sched_chunk = 16;           // RTOW_SCHED_CHUNK: fast builds: samples per work item in the bulk of a launch (0 = no
-                                  //   schedule: one item per stream and pixel, like the strict build)
-  double sched_ratio = 0.0;       // RTOW_SCHED_RATIO: > 0: the schedule ends on levels that shrink to single samples, each at
-                                  //   most 1/ratio of all the samples behind it, queue level-major (measured: worse than
-                                  //   exporting, the last level revisits the costly pixels right before the end); 0 = plain chunks
-  double budget_segs = 2.5;       // RTOW_BUDGET_SEGS: segments per sample assumed by the segment budget of an item
-  double budget_factor = 0.5;     // RTOW_BUDGET_FACTOR: the budget as a share of the time the queue still lasts
-  bool budget_off = false;        // RTOW_NO_EXPORT: items never export samples
-  int ovf_cap = 16384;            // RTOW_OVF_CAP: ring entries per workgroup
+  int sched_chunk = 10;           // RTOW_SCHED_CHUNK: fast builds: samples per work item aimed at (0 = one item per stream and
+                                  //   pixel, like the strict build).  5 / 10 / 20 / 25: 10.88 / 11.18 / 10.22 / 9.55 Gsamples/s on C2
   void read() {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
     auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
@@ -304,12 +297,7 @@ struct Knobs {
       }
     }
     bvh4_stack_k = std::min(std::max(geti("RTOW_BVH4_STACK_K", 0), 0), 64);
-    sched_chunk = std::min(std::max(geti("RTOW_SCHED_CHUNK", 16), 0), 4096);
-    sched_ratio = std::min(std::max(getd("RTOW_SCHED_RATIO", 0.0), 0.0), 16.0);
-    budget_segs = std::min(std::max(getd("RTOW_BUDGET_SEGS", 2.5), 0.01), 1000.0);
-    budget_factor = std::min(std::max(getd("RTOW_BUDGET_FACTOR", 0.5), 0.0), 100.0);
-    budget_off = std::getenv("RTOW_NO_EXPORT") != nullptr;
-    ovf_cap = std::min(std::max(geti("RTOW_OVF_CAP", 16384), 64), 1 << 20);
+    sched_chunk = std::min(std::max(geti("RTOW_SCHED_CHUNK", 10), 0), 4096);
   }
 };
 
@@ -352,16 +340,7 @@ struct rtow_ctx {
   unsigned built = 0;    // kNeed* bits of what the resident scene holds (rtow_render uploads only what its kernel reads)
   // workspace
   DevBuf partials, stack, counters, spill;
-  DevBuf ovf_desc, ovf_color;  // rings of exported samples (one per workgroup), see rtow_trace_body.h
-  uint32_t launch_serial = 0;  // tag of the ring entries of a launch (entries of earlier launches are stale, never cleared)
   DevBuf out, out8;  // rtow_render / rtow_render_rgb8: device-side output of the host-buffer entry points
-  // level table of the last render ([level][first sample, count], see make_schedule): device copy, pinned
-  // staging buffer, and the key it was built for
-  DevBuf lvl_dev;
-  uint32_t *lvl_pinned = nullptr;
-  size_t lvl_pinned_entries = 0;
-  std::vector<uint32_t> lvl_host;
-  long long lvl_key[4] = {-1, -1, -1, -1};
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
   int occ[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
@@ -416,9 +395,8 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
-                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->lvl_dev, &c->rtree, &c->ovf_desc, &c->ovf_color})
+                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->rtree})
     b->release();
-  if (c->lvl_pinned) (void)hipHostFree(c->lvl_pinned);
   if (c->arena.p) (void)hipHostFree(c->arena.p);
   for (int i = 0; i < kEventRing; ++i)
     for (int k = 0; k < 2; ++k)
@@ -897,65 +875,68 @@ int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t cap
   return n;
 }
 
-// The sample schedule of the fast builds: `total` consecutive samples per pixel, cut into levels.  Built from
-// the END of the launch: 1, 1, then each earlier level at most 1/ratio of everything after it, capped at
-// `chunk`; what is left over goes to the front in chunks (a short first chunk takes the remainder).  So the
-// bulk of a launch runs on items of `chunk` samples (few queue fetches and partial sums) and its end on items
-// of one sample: a work item taken late costs no more than the work still queued behind it, and what a wave
-// can be left holding when the queue runs dry is one path, not one item of many samples.
-static void make_schedule(uint32_t first, uint32_t total, uint32_t chunk, double ratio, std::vector<uint32_t> &out) {
-  std::vector<uint32_t> tail;  // in reverse order of execution
-  uint32_t sum = 0;
-  while (ratio > 0.0 && sum < total) {
-    uint32_t n = (uint32_t)((double)sum / ratio);
-    n = std::max(n, 1u);
-    n = std::min(n, chunk);
-    if (n >= chunk) break;  // from here on: plain chunks
-    n = std::min(n, total - sum);
-    tail.push_back(n);
-    sum += n;
+// Levels: what one work item per pixel covers.  Strict build: a level is a stream, spp / nstreams samples summed
+// in sample order, the partial images added in stream order — the reference's own decomposition
+// (src/render.cpp:169-185), bit for bit.  Fast builds (tolerance builds: FMA contraction already re-associates):
+// the SAME samples, cut into levels of a length that does not depend on nstreams — the divisor of the sample
+// range nearest RTOW_SCHED_CHUNK (10, the measured optimum of the item length) — so Config::nthreads keeps its
+// arithmetic meaning (which samples exist: spp / nthreads * nthreads) without setting the size of a work item: a
+// drop-in caller with the reference's default of 4 threads (25 or 125 samples per stream) runs the items the
+// bench runs.  The sum of a pixel is then the fixed-order sum of its level sums; the image is a pure function
+// of (scene, config, seed) and of nothing else.
+struct LevelPlan {
+  int spt;    // samples per level
+  int first;  // index of the first level: its first sample is first * spt
+  int count;  // levels
+};
+static LevelPlan level_plan(const rtow_config_t *cfg, int chunk) {
+  const int spt = cfg->samples_per_pixel / cfg->nstreams;  // src/render.cpp:174
+  const int streams_now = cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams;
+  LevelPlan p{spt, cfg->stream_first, streams_now};
+  if (cfg->precision == RTOW_F64_STRICT || chunk <= 0 || spt <= 0) return p;
+  // a level length d must divide the first sample index and the number of samples: any divisor of their gcd
+  const long long s0 = (long long)cfg->stream_first * spt, total = (long long)streams_now * spt;
+  long long g = total, r = s0;
+  while (r) {
+    const long long t = g % r;
+    g = r;
+    r = t;
   }
-  std::vector<uint32_t> sizes;
-  const uint32_t bulk = total - sum;
-  if (bulk % chunk) sizes.push_back(bulk % chunk);
-  for (uint32_t i = 0; i < bulk / chunk; ++i) sizes.push_back(chunk);
-  for (size_t i = tail.size(); i-- > 0;) sizes.push_back(tail[i]);
-  out.clear();
-  uint32_t at = first;
-  for (uint32_t n : sizes) {
-    out.push_back(at);
-    out.push_back(n);
-    at += n;
+  long long best = 1;
+  double best_err = 1e300;
+  for (long long d = 1; d * d <= g; ++d) {
+    if (g % d) continue;
+    for (long long e : {d, g / d}) {
+      const double err = std::fabs(std::log((double)e / (double)chunk));
+      if (err < best_err - 1e-12 || (std::fabs(err - best_err) <= 1e-12 && e < best)) {
+        best_err = err;
+        best = e;
+      }
+    }
   }
+  if (total / best > 0x7fffffffLL || best > 0x7fffffffLL) return p;
+  p.spt = (int)best;
+  p.first = (int)(s0 / best);
+  p.count = (int)(total / best);
+  return p;
 }
 
-// (diagnostic / tests) the level table a render of `cfg` uses on this context: pairs (first sample, count)
+// (diagnostic / tests) the levels a render of `cfg` is cut into: pairs (first sample, count).  ctx may be NULL.
 static int impl_debug_schedule(rtow_ctx *c, const rtow_config_t *cfg, uint32_t *out, int32_t capacity_pairs) {
   int rc = validate_cfg(cfg);
   if (rc) return rc;
   Knobs defaults;  // ctx NULL: the defaults of a new context (pure host arithmetic, usable without a GPU)
   if (!c) defaults.read();
-  const Knobs &kn = c ? c->knobs : defaults;
-  const uint32_t spt = (uint32_t)(cfg->samples_per_pixel / cfg->nstreams);
-  const uint32_t streams_now = (uint32_t)(cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams);
-  std::vector<uint32_t> t;
-  if (cfg->precision == RTOW_F64_STRICT || kn.sched_chunk == 0 || spt == 0)
-    for (uint32_t k = 0; k < streams_now; ++k) {
-      t.push_back(((uint32_t)cfg->stream_first + k) * spt);
-      t.push_back(spt);
-    }
-  else
-    make_schedule((uint32_t)cfg->stream_first * spt, streams_now * spt, (uint32_t)kn.sched_chunk, kn.sched_ratio, t);
-  const int n = (int)(t.size() / 2);
-  for (int i = 0; i < n && i < capacity_pairs && out; ++i) {
-    out[2 * i] = t[2 * i];
-    out[2 * i + 1] = t[2 * i + 1];
+  const LevelPlan p = level_plan(cfg, (c ? c->knobs : defaults).sched_chunk);
+  for (int i = 0; i < p.count && i < capacity_pairs && out; ++i) {
+    out[2 * i] = (uint32_t)(p.first + i) * (uint32_t)p.spt;
+    out[2 * i + 1] = (uint32_t)p.spt;
   }
-  return n;
+  return p.count;
 }
 
 static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
-                         rtow_stats_t *stats, int lvl_first, int lvl_count, int accumulate);
+                         rtow_stats_t *stats, const LevelPlan &plan, int lvl_first, int lvl_count, int accumulate);
 
 static int impl_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
                        rtow_stats_t *stats) {
@@ -965,7 +946,6 @@ static int impl_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb
   if (!c->have_scene) return fail(RTOW_ENOSCENE, "no scene uploaded");
   if (!d_rgb_sums) return fail(RTOW_EINVAL, "d_rgb_sums is NULL");
   HIPCHK(hipSetDevice(c->device));
-  hipStream_t st = (hipStream_t)hip_stream;
 
   const int rows = rtow_local_rows(cfg);
   const int spt = cfg->samples_per_pixel / cfg->nstreams;  // src/render.cpp:174
@@ -973,60 +953,25 @@ static int impl_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb
   const int streams_now = cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams;
   if ((unsigned long long)spt * (unsigned long long)(cfg->stream_first + streams_now) > 0xffffffffULL)
     return fail(RTOW_EINVAL, "sample index beyond 32 bits");
-  // ---- levels: what one work item per pixel covers (see decode_item in the kernel) ----
-  // strict build: level = stream, the reference's own decomposition (src/render.cpp:169-185), summed in its
-  // order.  Fast builds: a schedule over the same sample range, independent of nstreams (Config::nthreads keeps
-  // its arithmetic meaning — which samples exist — but no longer sets the size of a work item).
-  const bool scheduled = cfg->precision != RTOW_F64_STRICT && c->knobs.sched_chunk > 0 && spt > 0;
-  {
-    const long long key[4] = {scheduled ? c->knobs.sched_chunk : 0, (long long)cfg->stream_first * spt,
-                              (long long)streams_now * spt, scheduled ? -1 : spt};
-    if (std::memcmp(key, c->lvl_key, sizeof key) != 0) {
-      std::vector<uint32_t> &t = c->lvl_host;
-      t.clear();
-      if (scheduled) {
-        make_schedule((uint32_t)cfg->stream_first * (uint32_t)spt, (uint32_t)streams_now * (uint32_t)spt,
-                      (uint32_t)c->knobs.sched_chunk, c->knobs.sched_ratio, t);
-      } else {
-        for (int k = 0; k < streams_now; ++k) {
-          t.push_back((uint32_t)(cfg->stream_first + k) * (uint32_t)spt);
-          t.push_back((uint32_t)spt);
-        }
-      }
-      if ((rc = c->lvl_dev.ensure(t.size() * sizeof(uint32_t) + 16))) return rc;
-      // the pinned staging copy may still be the source of a copy queued by the previous call
-      HIPCHK(hipStreamSynchronize(st));
-      if (c->lvl_pinned_entries < t.size()) {
-        if (c->lvl_pinned) HIPCHK(hipHostFree(c->lvl_pinned));
-        c->lvl_pinned = nullptr;
-        c->lvl_pinned_entries = 0;
-        const size_t want = t.size() * 2 + 64;
-        HIPCHK(hipHostMalloc((void **)&c->lvl_pinned, want * sizeof(uint32_t), hipHostMallocDefault));
-        c->lvl_pinned_entries = want;
-      }
-      std::memcpy(c->lvl_pinned, t.data(), t.size() * sizeof(uint32_t));
-      HIPCHK(hipMemcpyAsync(c->lvl_dev.p, c->lvl_pinned, t.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-      std::memcpy(c->lvl_key, key, sizeof key);
-    }
-  }
-  const int n_levels = (int)(c->lvl_host.size() / 2);
+  const LevelPlan plan = level_plan(cfg, c->knobs.sched_chunk);
+  const int n_levels = plan.count;
   // Large sample counts: the per-level partial sums (24 B per pixel and level) are bounded by tracing the
   // levels in ranges that accumulate onto d_rgb_sums — bit-identical to one launch (the reduce kernel adds
   // level sums in level order either way).
   unsigned long long max_levels = (unsigned long long)n_levels;
   if (npix > 0) {
-    max_levels = c->knobs.partials_cap / (npix * 32ull);
-    if (0xfff00000ULL / npix < max_levels) max_levels = 0xfff00000ULL / npix;  // 32-bit item index
+    max_levels = c->knobs.partials_cap / (npix * 24ull);
+    if (0xfffffff0ULL / npix < max_levels) max_levels = 0xfffffff0ULL / npix;  // 32-bit item index
     if (max_levels < 1) max_levels = 1;
   }
   if ((unsigned long long)n_levels <= max_levels || spt == 0 || npix == 0)
-    return render_levels(c, cfg, d_rgb_sums, hip_stream, stats, 0, n_levels, cfg->accumulate);
+    return render_levels(c, cfg, d_rgb_sums, hip_stream, stats, plan, 0, n_levels, cfg->accumulate);
   rtow_stats_t total;
   std::memset(&total, 0, sizeof total);
   for (int done = 0; done < n_levels;) {
     const int now = (int)std::min<unsigned long long>(max_levels, (unsigned long long)(n_levels - done));
     rtow_stats_t st1;
-    rc = render_levels(c, cfg, d_rgb_sums, hip_stream, stats ? &st1 : nullptr, done, now,
+    rc = render_levels(c, cfg, d_rgb_sums, hip_stream, stats ? &st1 : nullptr, plan, done, now,
                        (done > 0 || cfg->accumulate) ? 1 : 0);
     if (rc) return rc;
     if (stats) {
@@ -1045,24 +990,17 @@ static int impl_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb
   return RTOW_OK;
 }
 
-// One launch: levels [lvl_first, lvl_first + lvl_count) of the context's level table.
+// One launch: levels [lvl_first, lvl_first + lvl_count) of the plan.
 static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
-                         rtow_stats_t *stats, int lvl_first, int lvl_count, int accumulate) {
+                         rtow_stats_t *stats, const LevelPlan &plan, int lvl_first, int lvl_count, int accumulate) {
   int rc;
   hipStream_t st = (hipStream_t)hip_stream;
   const int rows = rtow_local_rows(cfg);
   const unsigned long long npix = (unsigned long long)rows * cfg->image_width;
   const int streams_now = lvl_count;  // levels of this launch
+  const int spt = plan.spt;
   const unsigned long long n_items = npix * (unsigned long long)streams_now;
-  unsigned long long samples_per_pixel_now = 0;
-  int spt = 0;  // the longest level of this launch
-  for (int k = 0; k < lvl_count; ++k) {
-    const uint32_t n = c->lvl_host[2 * (size_t)(lvl_first + k) + 1];
-    samples_per_pixel_now += n;
-    spt = std::max(spt, (int)n);
-  }
-  const bool scheduled = c->lvl_key[0] > 0;
-  if (n_items > 0xfff00000ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
+  if (n_items > 0xfffffff0ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
   int kernel = cfg->kernel;
   // a handful of primitives is cheaper to stream than to walk
   // AUTO: a handful of primitives is cheaper to stream than to walk; sphere scenes walk the
@@ -1190,15 +1128,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   const unsigned long long n_lanes = (unsigned long long)grid * block;
 
   const size_t depth_slots = (size_t)(cfg->max_child_rays > 0 ? cfg->max_child_rays : 1);
-  const uint32_t ovf_cap = (uint32_t)c->knobs.ovf_cap;
-  {
-    // ring descriptors carry the tag of the launch that wrote them (never 0): fresh memory must not look tagged
-    const void *before = c->ovf_desc.p;
-    if ((rc = c->ovf_desc.ensure((size_t)grid * ovf_cap * 4 * sizeof(uint32_t)))) return rc;
-    if (c->ovf_desc.p != before) HIPCHK(hipMemsetAsync(c->ovf_desc.p, 0, c->ovf_desc.bytes, st));
-  }
-  if ((rc = c->partials.ensure((size_t)n_items * 4 * sizeof(double))) ||
-      (rc = c->ovf_color.ensure((size_t)grid * ovf_cap * 3 * sizeof(double))) ||
+  if ((rc = c->partials.ensure((size_t)n_items * 3 * sizeof(double))) ||
       (rc = c->stack.ensure(strict ? depth_slots * (size_t)n_lanes * sizeof(uint32_t) : 4)) ||  // strict build only
       (rc = c->counters.ensure(48 * sizeof(unsigned long long))))
     return rc;
@@ -1216,15 +1146,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   P.H = cfg->image_height;
   P.spt = spt;
   P.nstreams = streams_now;
-  P.level_major = scheduled && c->knobs.sched_ratio > 0.0 ? 1u : 0u;
-  P.lvl = (const uint32_t *)c->lvl_dev.p + 2 * (size_t)lvl_first;
-  // exported samples: one ring per workgroup; an item's segment budget is the number of trips the queue still
-  // lasts when it is fetched — items left * samples per item * segments per sample / lanes — times a factor
-  P.ovf_desc = (uint32_t *)c->ovf_desc.p;
-  P.ovf_color = (double *)c->ovf_color.p;
-  P.ovf_cap = ovf_cap;
-  P.ovf_tag = ++c->launch_serial ? c->launch_serial : ++c->launch_serial;  // (never 0)
-  P.budget_k = c->knobs.budget_off ? 1e30f : (float)(c->knobs.budget_segs * c->knobs.budget_factor / (double)n_lanes);
+  P.stream_first = plan.first + lvl_first;
   P.max_child_rays = cfg->max_child_rays;
   P.rank = cfg->rank;
   P.nranks = cfg->nranks;
@@ -1255,8 +1177,6 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   P.div_tpr_n = th ? (uint32_t)cfg->image_width >> tw : 1u;
   P.div_tpr = make_fastdiv(P.div_tpr_n);
   P.n_tile_rows = th ? (uint32_t)rows >> th : 1u;
-  P.n_tiles = th ? P.n_tile_rows * P.div_tpr_n : 1u;
-  P.div_ntiles = make_fastdiv(P.n_tiles);
   {
     const int eighths = c->knobs.sky_eighths;  // the top eighth of the image is traced last (RTOW_SKY_EIGHTHS: 0..8)
     P.sky_rows = th ? P.n_tile_rows * (uint32_t)eighths / 8u : 0u;
@@ -1310,7 +1230,6 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   }
   rtow::ReduceParams R;
   R.partials = P.partials;
-  R.ovf_color = P.ovf_color;
   R.out = (double *)d_rgb_sums;
   R.npix3 = (uint32_t)(npix * 3);
   R.nstreams = streams_now;
@@ -1337,7 +1256,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
       HIPCHK(hipEventElapsedTime(&ms, c->ev[slot][0], c->ev[slot][1]));
       stats->kernel_ms = ms;
     }
-    stats->samples = npix * samples_per_pixel_now;
+    stats->samples = npix * (unsigned long long)spt * (unsigned long long)streams_now;
     stats->segments = c->h_counters[1];
     if (kernel == RTOW_KERNEL_BRUTE) {
       stats->prim_tests = stats->segments * (unsigned long long)c->n_prims;

@@ -86,12 +86,12 @@ struct TraceParams {
   const float *cam32;      // the same 21 values as binary32 (f32 build)
                            // (by value it pinned 42 SGPRs across the whole kernel)
   int32_t W, H;            // full image
-  int32_t spt;             // the largest sample count of a level of this launch (bounds the tail protocol)
-  int32_t nstreams;        // LEVELS traced by this launch.  A level is a run of consecutive sample indices of every
-                           // pixel, one work item per pixel: a reference "thread" (stream, src/render.cpp:151-166) in
-                           // the strict build, a chunk of the launch's sample range in the fast builds (`lvl`)
-  uint32_t level_major;    // queue order: 0 = tile-major, level-minor (uniform streams); 1 = level-major, the
-                           // levels in table order, so that the launch ends on the shortest items
+  // A LEVEL is a run of `spt` consecutive samples of every pixel, one work item per pixel.  Strict build: a level
+  // is one reference "thread" (stream): spt = spp / nstreams (src/render.cpp:151-166, 174).  Fast builds: the
+  // launch's sample range is cut into levels by the host (rtow_capi.cpp, level_plan) whatever nstreams is.
+  int32_t spt;             // samples per level
+  int32_t nstreams;        // levels traced by THIS launch
+  int32_t stream_first;    // index of its first level (sample index = level * spt + s)
   int32_t max_child_rays;
   int32_t rank, nranks, tile_rows;
   int32_t local_rows;
@@ -99,22 +99,14 @@ struct TraceParams {
   uint32_t n_items;        // local_rows * W * nstreams
   uint32_t n_lanes;        // grid * block (stride of the path stack)
   FastDiv div_npix, div_w, div_tile;  // item -> (stream, row, column, strip)
-  FastDiv div_ns;                     // tiled order: (item / 64) -> (tile, level)
-  FastDiv div_ntiles;                 // level-major order: (item / 64) -> (level, tile)
-  uint32_t n_tiles;                   // 64-pixel tiles of this rank's rows
-  // exported samples (rtow_trace_body.h): one ring of `ovf_cap` entries per workgroup
-  uint32_t *ovf_desc;      // [grid][ovf_cap][4]  pixel, sample, tag of the launch, -
-  double *ovf_color;       // [grid][ovf_cap][3]  colour of the exported sample
-  uint32_t ovf_cap, ovf_tag;
-  float budget_k;          // segment budget of an item = items left in the queue * its samples * budget_k
-  const uint32_t *lvl;     // [nstreams][2]  first sample index, sample count of each level (device memory, scalar loads)
+  FastDiv div_ns;                     // tiled order: (item / 64) -> (tile, stream)
   // pixel order inside this rank's rows: tiles of 2^tile_w_log2 x 2^tile_h_log2 = 64 pixels,
   // tiles row-major (tile_h_log2 == 0 and tile_w_log2 == 0: plain row-major order)
   uint32_t tile_w_log2, tile_h_log2;
   FastDiv div_tpr;         // tiles per row = W >> tile_w_log2
   uint32_t div_tpr_n;      // the divisor itself
   uint32_t n_tile_rows, sky_rows;  // tiled order: tile rows of this rank, and how many of the top ones come last
-  double *partials;        // [level][local_rows*W][4]  colour sums + (ring slot << 32 | count) of the item's exported samples
+  double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   uint32_t *spill;         // BVH4 kernel: traversal stack entries beyond the LDS part, [entry][n_lanes]
   uint32_t b4_trips;       // BVH4: 1 = the trip-structured kernel (rtow_trace_body.h, default), 0 = the state machine
@@ -127,8 +119,7 @@ struct TraceParams {
 };
 
 struct ReduceParams {
-  const double *partials;  // [level][tiled pixel][4]: r g b sums, exported samples (ring slot << 32 | count)
-  const double *ovf_color; // colours of the exported samples, by ring slot
+  const double *partials;  // [stream][tiled pixel][3]
   double *out;             // [local_rows*W][3], row-major
   uint32_t npix3;          // local_rows*W*3
   int32_t nstreams;

@@ -1,9 +1,6 @@
 // Stream reduce: global_image = sum over streams of the partial images, added in
 // stream order exactly like the reference joins its threads
 // (src/render.cpp:176-180: global = done + global, futures taken in launch order).
-// An item whose lane exported its last samples (rtow_trace_body.h, "exported samples") stored the sum of the
-// samples it traced itself; the exported colours are added behind it in sample order, which makes the item's
-// sum the sequential one of src/render.cpp:156-165 bit for bit.
 #include <hip/hip_runtime.h>
 
 #include "rtow_device.h"
@@ -14,24 +11,16 @@ __global__ void __launch_bounds__(256) rtow_reduce_streams(const ReduceParams p)
   const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
   if (idx >= p.npix3) return;
   // where this value sits in the (possibly tiled) item order of the trace kernel
-  const uint32_t px = idx / 3u, c = idx - px * 3u;
-  uint32_t spx = px;
+  uint32_t src = idx;
   if (p.tile_h_log2 != 0u) {
+    const uint32_t px = idx / 3u, c = idx - px * 3u;
     const uint32_t lr = px / p.W, j = px - lr * p.W;
     const uint32_t tr = lr >> p.tile_h_log2, tc = j >> p.tile_w_log2;
     const uint32_t w = ((lr & ((1u << p.tile_h_log2) - 1u)) << p.tile_w_log2) | (j & ((1u << p.tile_w_log2) - 1u));
-    spx = ((tr * p.tiles_per_row + tc) << 6) | w;
+    src = (((tr * p.tiles_per_row + tc) << 6) | w) * 3u + c;
   }
-  const size_t npix = p.npix3 / 3u;
   double g = p.accumulate ? p.out[idx] : 0.0;
-  for (int k = 0; k < p.nstreams; ++k) {
-    const double *rec = p.partials + ((size_t)k * npix + spx) * 4;
-    double item = rec[c];
-    const unsigned long long meta = (unsigned long long)__double_as_longlong(rec[3]);
-    const uint32_t n = (uint32_t)meta, base = (uint32_t)(meta >> 32);
-    for (uint32_t i = 0; i < n; ++i) item = item + p.ovf_color[(size_t)(base + i) * 3 + c];
-    g = item + g;
-  }
+  for (int k = 0; k < p.nstreams; ++k) g = p.partials[(size_t)k * p.npix3 + src] + g;
   p.out[idx] = g;
 }
 // write_color on the device (src/render.cpp:11-20): c = sqrt(sum / spp), clamp to [0, 0.999],

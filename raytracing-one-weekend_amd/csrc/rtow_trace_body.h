@@ -86,7 +86,7 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDiv f) {
   return f.shift == 255u ? n : (((n - t) >> 1) + t) >> f.shift;  // shift 255: divisor 1
 }
 
-constexpr uint32_t kItemBatch = 64;  // work items fetched per global atomic (per wave): one 64-pixel tile of one level
+constexpr uint32_t kItemBatch = 64;  // work items fetched per global atomic (per wave)
 
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -101,62 +101,52 @@ __device__ __forceinline__ double lane_read(uint32_t src, double v) {
   const uint32_t lo = lane_read(src, (uint32_t)b), hi = lane_read(src, (uint32_t)(b >> 32));
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-__device__ __forceinline__ unsigned long long wave_bcast(unsigned long long v, int src_lane) {  // src_lane: wave-uniform
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
-  return ((unsigned long long)hi << 32) | lo;
-}
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 // ---- work items ------------------------------------------------------------------------------
-// A wave's share of the global item queue: one atomic buys a batch of 64 items — one 64-pixel tile of one
-// level — and the lanes take items from the wave-local pool [next, end) by ballot rank.  All fields are
-// wave-uniform.  (One atomic per wave TRIP saturated the counter word at ~100 dequeues/us.  Until round 3 the
-// batch shrank as the queue drained — "guided" batches against hoarding — which brought that storm back for
-// the last tenth of every launch: ~40 us per trip.  The end of a launch is balanced by splitting ITEMS now,
-// see "exported samples" below, and a batch is always a tile.)
+// A wave's share of the global item queue: one atomic buys a batch, lanes take items from the
+// wave-local pool [next, end) by ballot rank.  All fields are wave-uniform.
 struct ItemPool {
   uint32_t next = 0, end = 0;
-  bool dry = false;  // this wave has seen the end of the queue
-#ifdef RTOW_GUIDED
-  unsigned long long seen = 0ull;
-#endif
+  unsigned long long seen = 0ull;  // queue head as of this wave's last fetch
 };
 
 // Hands one queue position to every lane of `need_mask` (all lanes of the wave call this together).
-// Returns the lane's position, >= kp->n_items when the queue is exhausted (pool.dry is then set).
+// Returns the lane's position, >= kp->n_items when the queue is exhausted.
 __device__ __forceinline__ unsigned long long take_items(ItemPool &pool, unsigned long long need_mask, unsigned lane,
-                                                         const RTOW_CONST TraceParams *kp, unsigned long long *counters) {
+                                                         uint32_t n_waves, const RTOW_CONST TraceParams *kp,
+                                                         unsigned long long *counters) {
+  // Wave-local pool [next, end): one global atomic buys kItemBatch items, which the lanes then take by
+  // ballot rank with no further traffic (a single hot counter word saturates near 90 dequeues/us on this
+  // chip — one atomic per wave trip was the bottleneck).  All of this is wave-uniform except `mine`.
   const uint32_t want = (uint32_t)__popcll(need_mask);
   const uint32_t avail = pool.end - pool.next;
   const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
   unsigned long long mine = (unsigned long long)pool.next + rank;
   if (want > avail) {
-#ifdef RTOW_GUIDED
-    // (experiment: the round-2 guided batches — shrinking to what the wave needs as the queue drains)
-    const unsigned long long left_g = (unsigned long long)kp->n_items > pool.seen ? (unsigned long long)kp->n_items - pool.seen : 0ull;
-    uint32_t batch = (uint32_t)(left_g / ((unsigned long long)((gridDim.x * blockDim.x) >> 6) * 4ull));
+    // guided self-scheduling: 64 items per atomic while the queue is long, shrinking to
+    // exactly what this wave needs now as it drains (a wave that hoards items at the end
+    // of the queue keeps the whole launch waiting: measured ~4 item durations per launch)
+    const unsigned long long left =
+        (unsigned long long)kp->n_items > pool.seen ? (unsigned long long)kp->n_items - pool.seen : 0ull;
+    uint32_t batch = (uint32_t)(left / ((unsigned long long)n_waves * 4ull));
     batch = batch > kItemBatch ? kItemBatch : batch;
     batch = batch < want - avail ? want - avail : batch;
-#else
-    const uint32_t batch = kItemBatch;  // (want - avail <= 64)
-#endif
     const int leader = __ffsll((long long)need_mask) - 1;
-    unsigned long long base = (unsigned long long)kp->n_items;
-    // a wave that has seen the end of the queue stops polling it
-    if (!pool.dry) {
+    unsigned long long base = pool.seen;
+    // a wave that has seen the end of the queue stops polling it: at the end of a launch every
+    // wave asks every trip, and the one counter word serves ~100 requests/us (measured: the
+    // last trips of a launch took 34 us instead of 13)
+    if (pool.seen < (unsigned long long)kp->n_items) {
       if ((int)lane == leader) base = atomicAdd(&counters[0], (unsigned long long)batch);
-      base = wave_bcast(base, leader);
+      base = __shfl(base, leader);
     }
-    const unsigned long long cap = (unsigned long long)kp->n_items;
-#ifdef RTOW_GUIDED
-    pool.seen = base + batch;
-#endif
-    if (base + batch >= cap) pool.dry = true;
+    pool.seen = base + batch;  // how far the queue had advanced when this wave last looked
     if (rank >= avail) mine = base + (rank - avail);
     const unsigned long long nn = base + (want - avail), ne = base + batch;
+    const unsigned long long cap = (unsigned long long)kp->n_items;
     pool.next = (uint32_t)(nn < cap ? nn : cap);
     pool.end = (uint32_t)(ne < cap ? ne : cap);
   } else {
@@ -165,74 +155,30 @@ __device__ __forceinline__ unsigned long long take_items(ItemPool &pool, unsigne
   return mine;
 }
 
-// ---- exported samples ---------------------------------------------------------------------------
-// Per-pixel cost is heavy-tailed: the reference never absorbs a path (no Russian roulette), so in the
-// crevices between a sphere and the ground paths run to the bounce limit, and an item of 16 samples there
-// costs hundreds of trips — taken late, it IS the end of the launch (0.5 ms of a 8.3 ms frame in round 2,
-// when only the lanes of its own wave could take samples off it, five at a time, once the wave was idle).
-// Now every item has a SEGMENT BUDGET set when it is fetched: about the time the queue still lasts at that
-// point (long at the start of a launch, zero at its end).  A lane that starts a sample with its budget spent
-// EXPORTS the samples after it: their descriptors go to the ring of its workgroup (counters in LDS, entries in
-// HBM), and the lanes of the workgroup take ring entries before queue items.  An exported sample is traced
-// like any other; its colour goes to the ring entry's slot instead of a pixel sum, and the reduce kernel adds
-// the exported colours behind the item's own sum in sample order — so the pixel sum is the sequential one bit
-// for bit whoever traced what, in the strict build too.  The split point depends only on the item's own path
-// lengths, and where a full ring refuses an export the owner simply traces on: the image never depends on it.
-__shared__ uint32_t rtow_wg_head;  // ring entries reserved so far (may run past the capacity: clamp)
-__shared__ uint32_t rtow_wg_tail;  // ring entries claimed so far
-__shared__ uint32_t rtow_wg_busy;  // waves of the workgroup that still hold work (and so may still export)
-
-constexpr uint32_t kNoItem = 0xffffffffu;
-constexpr uint32_t kExported = 0x80000000u;  // `item` of a lane tracing an exported sample: flag | ring slot
-
-__device__ __forceinline__ void item_pools_init() {
-  if (threadIdx.x == 0) {
-    rtow_wg_head = 0u;
-    rtow_wg_tail = 0u;
-    rtow_wg_busy = blockDim.x >> 6;
-  }
-}
-
-// Queue position -> (partial-sum slot, column, global row, sample range).
-// A work item is (level, pixel): the level's run of consecutive samples of one pixel, summed in sample order.
-// Strict build: a level is one reference "thread" (stream): spp / nstreams samples (src/render.cpp:151-166).
-// Fast builds: the levels are a SCHEDULE over the launch's sample range, independent of nstreams — long chunks
-// first, then chunks that shrink geometrically down to single samples (rtow_capi.cpp, make_schedule) — and the
-// queue is level-major, so the launch ends on items of one sample and the end-of-launch tail is one path, not
-// one item.  The sum of a pixel is then the fixed-order sum of its level sums (tolerance build: re-association
-// of the reference's sum, like the contraction it already allows); the image stays a pure function of
-// (scene, config, seed).
-// Queue order.  Uniform levels: tile-major, level-minor — all streams of a 64-pixel tile are
+// Queue position -> (partial-sum slot, column, global row, first sample index).
+// Queue order.  Tiled mode: tile-major, stream-minor — all streams of a 64-pixel tile are
 // adjacent, tiles run top-to-bottom, and the queue is consumed from its far end, so a launch
 // ENDS on the top rows of the image for every stream.  In the reference's scenes that is sky
 // (the top 8 % of the cover image: one-segment paths), so most waves run out of work together:
 // waves finishing > 0.2 ms after they find the queue empty fell from 51 % to 5 % (+1.9 %).
 // (Stream-major order ended only the last stream on the sky; ending on the bottom rows —
-// near ground, short paths — measures the same.)  The partial-sum slot is [level][pixel] in both orders.
+// near ground, short paths — measures the same.)  The partial-sum slot stays [stream][pixel].
 struct ItemPos {
-  uint32_t item, j, gi, sample0, count;
+  uint32_t item, j, gi, sample0;
 };
 __device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp, uint32_t mine, uint32_t npix_local) {
   ItemPos ip;
   const uint32_t qi = kp->n_items - 1u - mine;
   uint32_t k, lp, lr;
-  if (kp->tile_h_log2 == 0u) {  // row-major, level-major
+  if (kp->tile_h_log2 == 0u) {  // row-major, stream-major
     k = fastdiv(qi, FastDiv{kp->div_npix.magic, kp->div_npix.shift});
     lp = qi - k * npix_local;
-    if (kp->level_major != 0u) k = (uint32_t)kp->nstreams - 1u - k;  // table order: the shortest levels last
     lr = fastdiv(lp, FastDiv{kp->div_w.magic, kp->div_w.shift});
     ip.j = lp - lr * (uint32_t)kp->W;
-  } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile of one level
+  } else {  // 64-pixel tiles: a wave's batch of 64 items is one compact tile of one stream
     const uint32_t g64 = qi >> 6, w = qi & 63u;
-    uint32_t t;
-    if (kp->level_major != 0u) {  // every level covers the image once, levels in table order
-      const uint32_t lq = fastdiv(g64, FastDiv{kp->div_ntiles.magic, kp->div_ntiles.shift});
-      t = g64 - lq * kp->n_tiles;
-      k = (uint32_t)kp->nstreams - 1u - lq;
-    } else {  // all levels of a tile adjacent
-      t = fastdiv(g64, FastDiv{kp->div_ns.magic, kp->div_ns.shift});
-      k = g64 - t * (uint32_t)kp->nstreams;
-    }
+    const uint32_t t = fastdiv(g64, FastDiv{kp->div_ns.magic, kp->div_ns.shift});
+    k = g64 - t * (uint32_t)kp->nstreams;
     const uint32_t trq = fastdiv(t, FastDiv{kp->div_tpr.magic, kp->div_tpr.shift});  // tile row by queue position
     const uint32_t tc = t - trq * (kp->div_tpr_n);
     // Tile rows are consumed from the highest position down.  Positions >= sky_rows hold the
@@ -248,20 +194,7 @@ __device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp,
   const uint32_t q = fastdiv(lr, FastDiv{kp->div_tile.magic, kp->div_tile.shift});
   const uint32_t rr = lr - q * (uint32_t)kp->tile_rows;
   ip.gi = (q * (uint32_t)kp->nranks + (uint32_t)kp->rank) * (uint32_t)kp->tile_rows + rr;
-  // The level's sample range, from the table in device memory.  The lanes of a fetch hold consecutive queue
-  // positions, i.e. one level or two: each distinct level costs one scalar load (a loop over the distinct values).
-  ip.sample0 = 0u;
-  ip.count = 0u;
-  const RTOW_CONST uint32_t *lvl = (const RTOW_CONST uint32_t *)kp->lvl;
-  for (bool todo = true; todo;) {
-    const uint32_t ku = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-    const uint32_t f = lvl[2u * ku], n = lvl[2u * ku + 1u];
-    if (k == ku) {
-      ip.sample0 = f;
-      ip.count = n;
-      todo = false;
-    }
-  }
+  ip.sample0 = (k + (uint32_t)kp->stream_first) * (uint32_t)kp->spt;  // first sample index of this stream
   return ip;
 }
 
@@ -358,7 +291,6 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
   [[maybe_unused]] const uint32_t lane_g = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t npix_local = (uint32_t)P.local_rows * (uint32_t)P.W;
 
-  item_pools_init();
   Image<LDS> im;
   im.g = KERNEL == 3 ? sc.gblob : sc.blob;
   [[maybe_unused]] Bvh4Reader<LDS> im4;  // LDS: the whole image is staged; otherwise the top of the tree
@@ -385,16 +317,14 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     const uint32_t n16 = (KERNEL == 3 ? sc.gblob_bytes : sc.blob_bytes) / 16u;
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     __syncthreads();
-  } else {
-    __syncthreads();  // the workgroup's item pool
   }
 
   // per-lane state
+  bool done = false;
   bool need_sample = true;
   bool pending_hit = false;   // the last segment ended in a hit that is scattered at the top of the next trip
   int s_left = 0;             // samples left in the current item
-  uint32_t item = kNoItem;    // partial-sum slot of the current item, or kExported | ring slot of an exported sample
-  uint32_t seg_limit = 0xffffffffu;  // value of nseg from which the item is over its segment budget
+  uint32_t item = 0xffffffffu;
   uint32_t j = 0;             // column
   uint32_t gi = 0;            // global row (from the top)
   V3d acc = {0.0, 0.0, 0.0};  // pixel_color of this item (src/render.cpp:156), binary64 in every build
@@ -416,8 +346,15 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
   Closest best;
   best.t = 0;
   best.prim = -1;
-  ItemPool pool;             // wave-uniform: this wave's batch of work items
-  bool counted_busy = true;  // wave-uniform: this wave is counted in rtow_wg_busy
+  // end-of-launch sample donation (see "tail" below)
+  bool helping = false;    // this lane traces a sample donated by another lane of the wave
+  bool holding = false;    // ... has finished it and keeps its colour in `acc` until the owner adds it
+  uint32_t partners = 0u;  // owner: stack of its helpers' lane ids (6 bits each, most recent lowest);
+                           // helper: its owner's lane id
+  int n_out = 0;           // owner: donated samples not yet added
+  uint32_t tail_trips = 0u;
+  ItemPool pool;  // wave-uniform: this wave's batch of work items
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   Stamps<STAMPS> stamps;
   stamps.start();
   unsigned long long t_empty = 0ull;  // diagnostic: when this wave first saw the queue empty
@@ -428,140 +365,142 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
 
   for (;;) {
     // ---- item bookkeeping ---------------------------------------------------
-    bool idle = need_sample && s_left <= 0;  // finished its item (or has none yet)
-    unsigned long long need_mask = __ballot(idle);
+    bool need_item = false;
+    if (!done && need_sample && s_left <= 0) {
+      if (helping) {  // a donated sample is finished: keep its colour for the owner
+        helping = false;
+        holding = true;
+        done = true;
+      } else if (n_out == 0) {
+        need_item = true;
+      }  // else: an owner waiting for donated samples
+    }
+    unsigned long long need_mask = __ballot(need_item);
     // Lanes that need a new item wait until `fetch_votes` of them do (or nothing else is left to do): with
     // 64 desynchronised lanes some lane finishes an item in almost every trip, and the fetch block — queue
-    // atomic, item decode, partial-sum store — would run every trip for two or three lanes.  (Not once the
-    // queue is dry: what is left then is exported samples, and nobody should wait for company.)
-    if (need_mask != 0ull && !pool.dry && (uint32_t)__popcll(need_mask) < P.fetch_votes && ~need_mask != 0ull)
+    // atomic, item decode, partial-sum store — would run every trip for two or three lanes.
+    if (need_mask != 0ull && (uint32_t)__popcll(need_mask) < P.fetch_votes && __ballot(!done && !need_item) != 0ull) {
       need_mask = 0ull;
+      need_item = false;
+    }
     if (need_mask != 0ull) {
       // The item-decoding parameters are read here from the kernel-argument segment (scalar loads)
       // instead of living in SGPRs for the whole launch: the kernel is VALU-issue-bound and ran out
       // of SGPRs, so every one of them cost a v_readlane (VALU) per use.
       const RTOW_CONST TraceParams *kp = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(kp));  // opaque per trip: keeps the loads from being hoisted out of the loop
-      const int leader = __ffsll((long long)need_mask) - 1;
-      if (idle && item != kNoItem) {  // the finished item goes to its partial-sum slot, an exported sample to its ring slot
-        double *dst = (item & kExported) != 0u ? kp->ovf_color + (size_t)(item & ~kExported) * 3
-                                               : kp->partials + (size_t)item * 4;
+      if (need_item && item != 0xffffffffu) {  // the finished item goes to its partial-sum slot
+        double *dst = P.partials + (size_t)item * 3;
         dst[0] = acc.x;
         dst[1] = acc.y;
         dst[2] = acc.z;
-        item = kNoItem;
+        item = 0xffffffffu;
       }
-      // (1) samples exported by the lanes of this workgroup come before new items
-#ifndef RTOW_NO_RING
-      {
-        uint32_t h = 0u, t = 0u;
-        if ((int)lane == leader) {
-          h = atomicAdd(&rtow_wg_head, 0u);
-          t = atomicAdd(&rtow_wg_tail, 0u);
-        }
-        h = (uint32_t)__builtin_amdgcn_readlane((int)h, leader);
-        t = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);
-        const uint32_t cap = kp->ovf_cap;
-        h = h < cap ? h : cap;
-        if (t < h) {
-          const uint32_t want = (uint32_t)__popcll(need_mask);
-          const uint32_t n = want < h - t ? want : h - t;
-          uint32_t ok = 0u;
-          if ((int)lane == leader) ok = atomicCAS(&rtow_wg_tail, t, t + n) == t ? 1u : 0u;
-          ok = (uint32_t)__builtin_amdgcn_readlane((int)ok, leader);
-          const uint32_t rank = (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
-          if (ok != 0u && idle && rank < n) {
-            const uint32_t slot = blockIdx.x * cap + t + rank;
-            // the entry was reserved before it was written: wait for its tag (the writer is a lane of this
-            // workgroup a few instructions behind its reservation — or of this wave, a trip ago)
-            const uint32_t *dp = kp->ovf_desc + (size_t)slot * 4;
-            uint32_t d_pixel = 0u, d_sample = 0u, spins = 0u;
-            for (;;) {
-              const uint32_t tag = __hip_atomic_load(dp + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (tag == kp->ovf_tag) {
-                d_pixel = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                d_sample = __hip_atomic_load(dp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                break;
-              }
-              if (++spins > (1u << 22)) {  // (structural bound; the host turns the flag into an error)
-                atomicAdd(&P.counters[47], 1ull);
-                break;
-              }
-              __builtin_amdgcn_s_sleep(1);
-            }
-            if (spins <= (1u << 22)) {
-              gi = fastdiv(d_pixel, FastDiv{kp->div_w.magic, kp->div_w.shift});
-              j = d_pixel - gi * (uint32_t)kp->W;
-              g.pixel = d_pixel;
-              g.sample = d_sample;
-              s_left = 1;
-              acc = {0.0, 0.0, 0.0};
-              item = kExported | slot;
-              seg_limit = 0xffffffffu;
-              idle = false;
-            }
+      const unsigned long long mine = take_items(pool, need_mask, lane, n_waves, kp, P.counters);
+      if (need_item) {
+        if (mine >= (unsigned long long)kp->n_items) {
+          done = true;
+          if constexpr (STAMPS) {
+            if (t_empty == 0ull) t_empty = __builtin_amdgcn_s_memrealtime();
           }
-        }
-      }
-#endif
-      // (2) the queue
-      const unsigned long long rest_mask = __ballot(idle);
-      if (rest_mask != 0ull && !(pool.dry && pool.next >= pool.end)) {
-        const unsigned long long mine = take_items(pool, rest_mask, lane, kp, P.counters);
-        if (idle && mine < (unsigned long long)kp->n_items) {
+        } else {
           const ItemPos ip = decode_item(kp, (uint32_t)mine, npix_local);
           item = ip.item;
           j = ip.j;
           gi = ip.gi;
           g.pixel = gi * (uint32_t)kp->W + j;
           g.sample = ip.sample0;
-          s_left = (int)ip.count;
+          s_left = kp->spt;
           acc = {0.0, 0.0, 0.0};
-          reinterpret_cast<unsigned long long *>(kp->partials)[(size_t)item * 4 + 3] = 0ull;  // no exported samples (yet)
-          // segment budget: about the trips the queue still lasts from here on
-          const float bud = (float)(kp->n_items - (uint32_t)mine) * (float)ip.count * kp->budget_k;
-          seg_limit = nseg + (bud < 1e9f ? (uint32_t)bud : 0x3fffffffu);
-          idle = false;
-        }
-        if constexpr (STAMPS) {
-          if (pool.dry && t_empty == 0ull) t_empty = __builtin_amdgcn_s_memrealtime();
         }
       }
     }
-    // ---- end of the launch -------------------------------------------------------------------
-    // A wave without work stays while other waves of its workgroup hold items: they may still export samples.
-    if (__ballot(!(need_sample && s_left <= 0)) == 0ull) {
-#ifdef RTOW_NO_RING
-      if (pool.dry && pool.next >= pool.end) break;
-#else
-      if (pool.dry && pool.next >= pool.end) {
-        uint32_t busy = 0u, h = 0u, t = 0u;
-        if (lane == 0u) {
-          if (counted_busy) (void)atomicSub(&rtow_wg_busy, 1u);
-          busy = atomicAdd(&rtow_wg_busy, 0u);
-          h = atomicAdd(&rtow_wg_head, 0u);
-          t = atomicAdd(&rtow_wg_tail, 0u);
+    // ---- tail: sample donation ------------------------------------------------------------
+    // Once the queue is empty a wave is as slow as its slowest lane's item (up to spt samples of
+    // up to max_child_rays segments each) while its other lanes idle.  An idle lane therefore
+    // takes over the LAST unstarted
+    // sample of a lane that still has two or more to go.  The owner adds the donated colours
+    // after its own samples, in sample order (most recent donation first), so the pixel sum is
+    // the sequential one bit for bit.  Only lanes of the same wave trade (registers + ds_bpermute).
+    // Measured: +0.9 % on C2.  What remains of the tail is one PATH: a trip takes ~13.7 us with four
+    // waves per SIMD, so a 50-bounce path started just before the queue empties runs ~0.2-0.7 ms.
+    if (__ballot(done) != 0ull) {
+      // (1) owners that have finished their own samples take the next donated colour, if ready
+      const bool ready = !done && need_sample && s_left <= 0 && n_out > 0;
+      if (__ballot(ready) != 0ull) {
+        const uint32_t h = partners & 63u;
+        const uint32_t src = ready ? h : lane;
+        // (not `ready && lane_read(..)`: short-circuit evaluation would run the cross-lane read with
+        // only the ready lanes active, and an inactive source lane reads as 0)
+        const uint32_t partner_holds = lane_read(src, (uint32_t)holding);
+        const bool take = ready && partner_holds != 0u;
+        const V3d c = {lane_read(src, acc.x), lane_read(src, acc.y), lane_read(src, acc.z)};
+        // a holding helper asks its owner whether it was the one taken
+        const uint32_t ow = holding ? partners : lane;
+        const bool o_take = lane_read(ow, (uint32_t)take) != 0u;
+        const uint32_t o_h = lane_read(ow, h);
+        if (take) {
+          acc = acc + c;
+          partners >>= 6;
+          --n_out;
         }
-        counted_busy = false;
-        busy = (uint32_t)__builtin_amdgcn_readfirstlane((int)busy);
-        h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        h = h < P.ovf_cap ? h : P.ovf_cap;
-        if (busy == 0u && t >= h) break;
-        if (t >= h) __builtin_amdgcn_s_sleep(16);
+        if (holding && o_take && o_h == lane) holding = false;
       }
-#endif
-      continue;
+      // (2) idle lanes take the last unstarted sample of lanes with >= 2 samples to go
+      const bool can_give = !done && !helping && s_left >= 2 && n_out < 5;
+      const bool can_help = done && !holding;
+      const unsigned long long gm = __ballot(can_give), hm = __ballot(can_help);
+      if (gm != 0ull && hm != 0ull) {
+        const uint32_t ng = (uint32_t)__popcll(gm), nh = (uint32_t)__popcll(hm);
+        const uint32_t cnt = ng < nh ? ng : nh;
+        const uint32_t grank = lanes_below(gm), hrank = lanes_below(hm);
+        // compaction (a permutation of the lanes): lane k learns the k-th giver / k-th helper
+        const uint32_t giver_k = (uint32_t)__builtin_amdgcn_ds_permute(
+            (int)((can_give ? grank : ng + (lane - grank)) << 2), (int)lane);
+        const uint32_t helper_k = (uint32_t)__builtin_amdgcn_ds_permute(
+            (int)((can_help ? hrank : nh + (lane - hrank)) << 2), (int)lane);
+        const bool gives = can_give && grank < cnt;
+        const bool helps = can_help && hrank < cnt;
+        const uint32_t my_giver = lane_read(helps ? hrank : lane, giver_k);
+        const uint32_t my_helper = lane_read(gives ? grank : lane, helper_k);
+        const uint32_t gsrc = helps ? my_giver : lane;
+        const uint32_t o_j = lane_read(gsrc, j), o_gi = lane_read(gsrc, gi);
+        const uint32_t o_pixel = lane_read(gsrc, g.pixel), o_sample = lane_read(gsrc, g.sample);
+        const uint32_t o_left = lane_read(gsrc, (uint32_t)s_left);
+        if (gives) {
+          s_left -= 1;
+          partners = (partners << 6) | my_helper;
+          ++n_out;
+        }
+        if (helps) {
+          j = o_j;
+          gi = o_gi;
+          g.pixel = o_pixel;
+          g.sample = o_sample + o_left - 1u;  // the giver's last sample
+          s_left = 1;
+          need_sample = true;
+          acc = {0.0, 0.0, 0.0};
+          helping = true;
+          done = false;
+          partners = my_giver;
+        }
+      }
+      // structural bound on the tail (every wait above ends when a bounded path ends; this makes
+      // the exit independent of that argument): give up donating, never hang
+      // (x64: a stopped-and-resumed walk spreads one segment over several trips)
+      if (++tail_trips > 64u * (4096u + 8u * (uint32_t)(P.max_child_rays + 2) * (uint32_t)(P.spt + 1))) {
+        if (!done || holding) atomicAdd(&P.counters[47], 1ull);  // samples dropped: the host turns this into an error
+        done = true;
+        helping = false;
+        holding = false;
+        n_out = 0;
+      }
     }
-#ifndef RTOW_NO_RING
-    if (!counted_busy) {  // (took exported samples after having run out of work)
-      if (lane == 0u) (void)atomicAdd(&rtow_wg_busy, 1u);
-      counted_busy = true;
-    }
-#endif
+    if (__ballot(!done || holding) == 0ull) break;
     stamps.mark(RG_FETCH);
 
-    const bool live = !(need_sample && s_left <= 0);
+    // (a lane whose fresh item has no samples — spt == 0 — goes straight back for the next one)
+    const bool live = !done && !(need_sample && s_left <= 0);
 
     // ---- new rays ------------------------------------------------------------------------------------
     // Two kinds of lanes need a new ray before the walk: those starting a sample (pixel jitter +
@@ -574,38 +513,6 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     // (counter = (request, sample, pixel)), so nothing changes in the image.
     const bool do_regen = live && need_sample;
     const bool do_scat = live && pending_hit;
-    // ---- export: a lane about to start a sample with its item's segment budget spent hands the samples
-    // AFTER this one to its workgroup (see "exported samples" above)
-#ifndef RTOW_NO_RING
-    {
-      const bool exp = do_regen && (item & kExported) == 0u && s_left >= 2 && nseg >= seg_limit;
-      if (__ballot(exp) != 0ull) {
-        if (exp) {
-          const uint32_t r = (uint32_t)s_left - 1u;
-          const uint32_t idx = atomicAdd(&rtow_wg_head, r);
-          const uint32_t cap = P.ovf_cap;
-          const uint32_t n = idx >= cap ? 0u : (cap - idx < r ? cap - idx : r);  // (a full ring: the owner traces on)
-          const uint32_t base = blockIdx.x * cap + idx;
-          const uint32_t first = g.sample + (uint32_t)s_left - n;  // the LAST n samples of the item
-          for (uint32_t i = 0; i < n; ++i) {
-            uint32_t *dp = P.ovf_desc + (size_t)(base + i) * 4;
-            dp[0] = g.pixel;
-            dp[1] = first + i;
-            __hip_atomic_store(dp + 2, P.ovf_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          if (n != 0u) {
-            reinterpret_cast<unsigned long long *>(P.partials)[(size_t)item * 4 + 3] = ((unsigned long long)base << 32) | n;
-            s_left -= (int)n;
-          }
-          seg_limit = 0xffffffffu;  // once per item
-        }
-        // (producer and consumers of a ring are waves of ONE workgroup, i.e. of one CU and its L1: workgroup
-        // scope.  Agent scope costs an L2 write-back / invalidate per export and per claim on this chip — its
-        // XCDs do not share an L2 — and measured 3x the whole launch.)
-        __threadfence_block();
-      }
-    }
-#endif
     V3 where = {0, 0, 0}, normal = {0, 0, 0};
     bool front = true;
     int mi = 0, kind = 0;

@@ -35,7 +35,6 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
   const uint32_t npix_local = (uint32_t)P.local_rows * (uint32_t)P.W;
   const uint32_t kRestartVotes = P.sm4_restart, kScatterVotes = P.sm4_scatter, kLeafVotes = P.sm4_leaf;  // (wave-uniform)
 
-  item_pools_init();
   Bvh4Reader<FULL> im;
   im.g = sc.blob4;
   im.lds_limit = sc.b4_lds_limit;
@@ -71,7 +70,8 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
   Rng g = {0, 0, 0};
   uint32_t nseg = 0, nnode = 0, nprim = 0;
   ItemPool pool;
-    Stamps<STAMPS> stamps;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  Stamps<STAMPS> stamps;
   stamps.start();
   if constexpr (STAMPS) {
     if (lane == 0) atomicMin(P.t_origin, (unsigned long long)__builtin_amdgcn_s_memrealtime());
@@ -122,14 +122,13 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
         if (need_mask != 0ull) {
           const RTOW_CONST TraceParams *kp = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
           asm volatile("" : "+s"(kp));  // opaque per trip: keeps the loads from being hoisted out of the loop
-          if (need_item && item != 0xffffffffu) {  // (records of 4 doubles: the 4th says "no exported samples")
-            double *dst = P.partials + (size_t)item * 4;
+          if (need_item && item != 0xffffffffu) {
+            double *dst = P.partials + (size_t)item * 3;
             dst[0] = acc.x;
             dst[1] = acc.y;
             dst[2] = acc.z;
-            dst[3] = 0.0;
           }
-          const unsigned long long mine = take_items(pool, need_mask, lane, kp, P.counters);
+          const unsigned long long mine = take_items(pool, need_mask, lane, n_waves, kp, P.counters);
           if (need_item) {
             if (mine >= (unsigned long long)kp->n_items) {
               phase = PH_DEAD;
@@ -141,7 +140,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
               gi = ip.gi;
               g.pixel = gi * (uint32_t)kp->W + j;
               g.sample = ip.sample0;
-              s_left = (int)ip.count;
+              s_left = kp->spt;
               acc = {0.0, 0.0, 0.0};
               phase = s_left > 0 ? PH_SAMPLE : PH_ITEM;
             }

@@ -203,37 +203,31 @@ def _schedule(cfg):
     return [(pairs[2 * i], pairs[2 * i + 1]) for i in range(n)]
 
 
-@pytest.mark.parametrize("spp,ns", [(100, 10), (100, 4), (500, 4), (7, 3), (1, 1), (16, 1), (1024, 64)])
+@pytest.mark.parametrize("spp,ns", [(100, 10), (100, 4), (500, 4), (99, 3), (7, 3), (1, 1), (16, 1), (1024, 64), (97, 1)])
 def test_fast_build_schedule_properties(spp, ns, monkeypatch):
-    """The levels a fast-build render is cut into (pure host arithmetic): they tile the effective sample
-    range, do not depend on nstreams beyond the effective spp and are at most RTOW_SCHED_CHUNK long; with
-    RTOW_SCHED_RATIO (an experiment: shrinking levels, level-major queue) they end on a single sample and from
-    the shrinking part on no level is longer than the work queued behind it."""
+    """The levels a fast-build render is cut into (pure host arithmetic): equal runs that tile the effective
+    sample range, of the divisor of the range nearest RTOW_SCHED_CHUNK (10) — whatever nstreams is; the strict
+    build keeps one level per stream, the reference's decomposition (src/render.cpp:169-185)."""
     monkeypatch.delenv("RTOW_SCHED_CHUNK", raising=False)
-    monkeypatch.delenv("RTOW_SCHED_RATIO", raising=False)
-    plain = _schedule(rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST))
-    assert plain[0][0] == 0 and sum(c for _, c in plain) == spp // ns * ns
-    assert all(a + c == b for (a, c), (b, _) in zip(plain, plain[1:])) and all(1 <= c <= 16 for _, c in plain)
-    assert all(c == 16 for _, c in plain[1:])  # chunks; the first one takes the remainder
-    monkeypatch.setenv("RTOW_SCHED_RATIO", "1.3")
     eff = spp // ns * ns
-    cfg = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST)
-    s = _schedule(cfg)
+    s = _schedule(rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST))
     assert s[0][0] == 0 and sum(c for _, c in s) == eff
     assert all(a + c == b for (a, c), (b, _) in zip(s, s[1:]))
-    assert all(1 <= c <= 16 for _, c in s) and s[-1][1] == 1
-    counts = [c for _, c in s]
-    for i, c in enumerate(counts[:-1]):
-        if c < 16 and i > 0:  # (the first level may be the short remainder)
-            assert c <= max(1, sum(counts[i + 1:])), (i, counts)
-    # the same effective spp through another stream count: the same table
-    other = rtow.make_config(64, 48, eff, 1, 10, precision=rtow.F64_FAST)
-    assert _schedule(other) == s
-    # strict build: one level per stream, the reference's decomposition (src/render.cpp:169-185)
+    d = s[0][1]
+    assert all(c == d for _, c in s) and eff % d == 0
+    import math
+    best = min((e for e in range(1, eff + 1) if eff % e == 0), key=lambda e: (abs(math.log(e / 10)), e))
+    assert d == best
+    # the same effective spp through another stream count: the same levels
+    assert _schedule(rtow.make_config(64, 48, eff, 1, 10, precision=rtow.F64_FAST)) == s
+    # strict build: one level per stream
     strict = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_STRICT)
     assert _schedule(strict) == [(k * (spp // ns), spp // ns) for k in range(ns)]
-    # a stream range covers its own samples
+    # a stream range covers its own samples, in levels that divide its first sample index too
     if ns >= 2:
         part = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST, stream_first=1, stream_count=ns - 1)
         ps = _schedule(part)
         assert ps[0][0] == spp // ns and sum(c for _, c in ps) == (ns - 1) * (spp // ns)
+        assert all(c == ps[0][1] for _, c in ps) and ps[0][0] % ps[0][1] == 0
+    monkeypatch.setenv("RTOW_SCHED_CHUNK", "0")  # off: the strict build's levels
+    assert _schedule(rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST)) == _schedule(strict)
