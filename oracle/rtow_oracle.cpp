@@ -791,8 +791,11 @@ inline bool fast_hit(const World &w, const FastTree &t, const Ray &r, double tmi
     // through their entry distance here (a stale entry costs tests, never a wrong hit)
     const int near = ta <= tb ? n.left : n.left + 1, far = ta <= tb ? n.left + 1 : n.left;
     const double tn = ta <= tb ? ta : tb, tf = ta <= tb ? tb : ta;
-    if (tf != INFINITY && sp < 127) stack[sp++] = far;
-    if (tn != INFINITY && sp < 127) stack[sp++] = near;
+    // (a full stack would drop a subtree and give a wrong-but-green reference image: hard error instead;
+    // the SAH tree's depth is ~2 log2 n, far below 128, so this never fires on a sane tree)
+    if ((tf != INFINITY) + (tn != INFINITY) + sp > 128) std::abort();
+    if (tf != INFINITY) stack[sp++] = far;
+    if (tn != INFINITY) stack[sp++] = near;
   }
   return any;
 }

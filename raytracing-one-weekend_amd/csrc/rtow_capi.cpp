@@ -248,9 +248,9 @@ struct Knobs {
   int fetch_votes = 0;            // RTOW_FETCH_VOTES: lanes that must need a work item before the fetch block runs
                                   // (0 = per kernel: 4, BVH4 2 — 2 / 4 / 8: C4 4.01 / 3.99 / 3.89, C5 1.98 / 1.96 / 1.92, C2 10.72 / 10.73 / 10.71)
   int leaf_votes = 0;             // RTOW_LEAF_VOTES: lanes that must hold a queued cell / leaf before a leaf phase
-                                  //   (0 = per kernel: GRID 16, BVH4 24)
+                                  //   (0 = per kernel: GRID 16, BVH4 28)
   int walk_cap = -1, walk_max_open = 0;  // RTOW_WALK_CAP=cap,max_open | off: resumable walk (-1 = per kernel:
-                                         //   GRID 3,16; BVH4 4,24 with the image in LDS, 4,40 otherwise)
+                                         //   GRID 3,16; BVH4 4,24 with every node in LDS, 4,32 otherwise)
   bool bvh4_sm = false;           // RTOW_BVH4_SM: the state-machine form of the BVH4 kernel (rtow_trace_sm4.h)
   int sm4_votes[3] = {8, 16, 16};  // RTOW_SM4_VOTES=restart,scatter,leaf: quorum of the state machine's blocks
   int bvh4_stack_k = 0;           // RTOW_BVH4_STACK_K: image staged whole if this many stack entries per lane still fit
@@ -341,6 +341,11 @@ struct rtow_ctx {
   // workspace
   DevBuf partials, stack, counters, spill;
   DevBuf out, out8;  // rtow_render / rtow_render_rgb8: device-side output of the host-buffer entry points
+  // rtow_render_rgb8: the reduce kernel of the next single-launch render writes bytes here instead of sums
+  unsigned char *fuse_rgb8 = nullptr;
+  double fuse_spp = 0.0;
+  bool fuse_used = false;
+  DevBuf counters_init;  // what the 48 counters look like before a launch (one D2D copy instead of three memsets)
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
   int occ[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
@@ -395,7 +400,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
-                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->rtree})
+                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->rtree, &c->counters_init})
     b->release();
   if (c->arena.p) (void)hipHostFree(c->arena.p);
   for (int i = 0; i < kEventRing; ++i)
@@ -1213,9 +1218,13 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   P.t_origin = P.counters + 16;
 
   if (stats) HIPCHK(hipEventRecord(c->call_ev[0], st));
-  HIPCHK(hipMemsetAsync(c->counters.p, 0, 48 * sizeof(unsigned long long), st));
-  HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 5, 0xff, sizeof(unsigned long long), st));   // min end
-  HIPCHK(hipMemsetAsync((unsigned long long *)c->counters.p + 16, 0xff, sizeof(unsigned long long), st));  // t_origin
+  if (!c->counters_init.p) {  // zeros, except the two minima of the diagnostic build ([5] min end, [16] t_origin)
+    std::vector<unsigned long long> init(48, 0ull);
+    init[5] = init[16] = ~0ull;
+    if ((rc = c->counters_init.ensure(48 * sizeof(unsigned long long)))) return rc;
+    HIPCHK(hipMemcpy(c->counters_init.p, init.data(), 48 * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemcpyAsync(c->counters.p, c->counters_init.p, 48 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
   const int slot = c->ev_count < kEventRing ? c->ev_count : -1;
   if (slot >= 0) HIPCHK(hipEventRecord(c->ev[slot][0], st));
   int launch_kernel = kernel;
@@ -1238,6 +1247,13 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   R.tile_w_log2 = tw;
   R.tile_h_log2 = th;
   R.tiles_per_row = P.div_tpr_n;
+  R.rgb8 = nullptr;
+  R.spp = 0.0;
+  if (c->fuse_rgb8 && lvl_first == 0 && lvl_count == plan.count && !accumulate) {  // the whole render in this launch
+    R.rgb8 = c->fuse_rgb8;
+    R.spp = c->fuse_spp;
+    c->fuse_used = true;
+  }
   lrc = rtow::launch_reduce(R, st);
   if (lrc != 0) return fail(RTOW_EHIP, "reduce kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
 
@@ -1401,8 +1417,12 @@ static int impl_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_c
     return RTOW_OK;
   }
   if ((rc = c->out.ensure(n * sizeof(double))) || (rc = c->out8.ensure(n))) return rc;  // kept across calls
+  c->fuse_rgb8 = (unsigned char *)c->out8.p;  // write_color inside the reduce kernel when the render is one launch
+  c->fuse_spp = (double)spp_eff;
+  c->fuse_used = false;
   rc = rtow_render_device(c, cfg, c->out.p, nullptr, stats);
-  if (rc == RTOW_OK) rc = rtow_tonemap_device(c, c->out.p, (int64_t)n, spp_eff, c->out8.p, nullptr);
+  c->fuse_rgb8 = nullptr;
+  if (rc == RTOW_OK && !c->fuse_used) rc = rtow_tonemap_device(c, c->out.p, (int64_t)n, spp_eff, c->out8.p, nullptr);
   if (rc == RTOW_OK) HIPCHK(hipMemcpy(rgb8_host, c->out8.p, n, hipMemcpyDeviceToHost));
   return rc;
 }

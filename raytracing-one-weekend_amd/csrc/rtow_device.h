@@ -125,6 +125,8 @@ struct ReduceParams {
   int32_t nstreams;
   int32_t accumulate;      // start from the sums already in `out`
   uint32_t W, tile_w_log2, tile_h_log2, tiles_per_row;
+  unsigned char *rgb8;     // not NULL: write_color(sum / spp) as bytes instead of the sums (rtow_render_rgb8)
+  double spp;
 };
 
 // launchers, one pair per arithmetic mode (separate translation units compiled

@@ -21,7 +21,16 @@ __global__ void __launch_bounds__(256) rtow_reduce_streams(const ReduceParams p)
   }
   double g = p.accumulate ? p.out[idx] : 0.0;
   for (int k = 0; k < p.nstreams; ++k) g = p.partials[(size_t)k * p.npix3 + src] + g;
-  p.out[idx] = g;
+  if (p.rgb8 != nullptr) {
+    // write_color fused into the reduce (rtow_render_rgb8: the f64 sums never go to memory); the same
+    // operations as rtow_tonemap_u8 below, so the bytes are the same
+    double c = sqrt(g / p.spp);
+    c = c < 0.0 ? 0.0 : (c > 0.999 ? 0.999 : c);
+    const int v = (int)(256.0 * c);
+    p.rgb8[idx] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  } else {
+    p.out[idx] = g;
+  }
 }
 // write_color on the device (src/render.cpp:11-20): c = sqrt(sum / spp), clamp to [0, 0.999],
 // int(256 * c) — one byte per channel.  f64 sqrt and division are the correctly rounded IEEE

@@ -131,9 +131,14 @@ __device__ __forceinline__ unsigned long long take_items(ItemPool &pool, unsigne
     // of the queue keeps the whole launch waiting: measured ~4 item durations per launch)
     const unsigned long long left =
         (unsigned long long)kp->n_items > pool.seen ? (unsigned long long)kp->n_items - pool.seen : 0ull;
+#ifdef RTOW_NO_SHRINK  // (experiment: a batch is always one tile)
+    uint32_t batch = kItemBatch;
+    (void)left;
+#else
     uint32_t batch = (uint32_t)(left / ((unsigned long long)n_waves * 4ull));
     batch = batch > kItemBatch ? kItemBatch : batch;
     batch = batch < want - avail ? want - avail : batch;
+#endif
     const int leader = __ffsll((long long)need_mask) - 1;
     unsigned long long base = pool.seen;
     // a wave that has seen the end of the queue stops polling it: at the end of a launch every
