@@ -101,6 +101,12 @@ __device__ __forceinline__ double lane_read(uint32_t src, double v) {
   const uint32_t lo = lane_read(src, (uint32_t)b), hi = lane_read(src, (uint32_t)(b >> 32));
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+__device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {  // src_lane: wave-uniform (v_readlane)
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src_lane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src_lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
@@ -430,6 +436,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     // Measured: +0.9 % on C2.  What remains of the tail is one PATH: a trip takes ~13.7 us with four
     // waves per SIMD, so a 50-bounce path started just before the queue empties runs ~0.2-0.7 ms.
     if (__ballot(done) != 0ull) {
+#ifdef RTOW_DONATE_R2  // (the round-2 form: at most 5 samples out per giver, lane ids on a 6-bit stack)
       // (1) owners that have finished their own samples take the next donated colour, if ready
       const bool ready = !done && need_sample && s_left <= 0 && n_out > 0;
       if (__ballot(ready) != 0ull) {
@@ -451,8 +458,35 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         }
         if (holding && o_take && o_h == lane) holding = false;
       }
-      // (2) idle lanes take the last unstarted sample of lanes with >= 2 samples to go
       const bool can_give = !done && !helping && s_left >= 2 && n_out < 5;
+#else
+      // (1) owners that have finished their own samples add the donated colours that are ready, in sample
+      // order: the owner's next sample index is the lowest donated one; its holder is found by ballot and
+      // read with v_readlane (round 3: no stack of helper ids in the owner, so every unstarted sample of an
+      // item can be out at once — a costly item met at the end of a launch used to take two rounds of five)
+      unsigned long long rm = __ballot(!done && need_sample && s_left <= 0 && n_out > 0);
+      while (rm != 0ull) {
+        const int o = __ffsll((long long)rm) - 1;  // (wave-uniform)
+        rm &= rm - 1ull;
+        const uint32_t want_sample = (uint32_t)__builtin_amdgcn_readlane((int)g.sample, o);
+        const uint32_t want_pixel = (uint32_t)__builtin_amdgcn_readlane((int)g.pixel, o);
+        const unsigned long long held =
+            __ballot(holding && partners == (uint32_t)o && g.sample == want_sample + 1u && g.pixel == want_pixel);
+        if (held != 0ull) {
+          const int h = __ffsll((long long)held) - 1;
+          const V3d c = {wave_bcast_f64(acc.x, h), wave_bcast_f64(acc.y, h), wave_bcast_f64(acc.z, h)};
+          if ((int)lane == o) {
+            acc = acc + c;
+            ++g.sample;
+            --n_out;
+          }
+          if ((int)lane == h) holding = false;
+          if (__builtin_amdgcn_readlane(n_out, o) > 0) rm |= 1ull << o;  // its next colour may be ready as well
+        }
+      }
+      const bool can_give = !done && !helping && s_left >= 2;
+#endif
+      // (2) idle lanes take the last unstarted sample of lanes with >= 2 samples to go
       const bool can_help = done && !holding;
       const unsigned long long gm = __ballot(can_give), hm = __ballot(can_help);
       if (gm != 0ull && hm != 0ull) {
@@ -462,19 +496,23 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         // compaction (a permutation of the lanes): lane k learns the k-th giver / k-th helper
         const uint32_t giver_k = (uint32_t)__builtin_amdgcn_ds_permute(
             (int)((can_give ? grank : ng + (lane - grank)) << 2), (int)lane);
-        const uint32_t helper_k = (uint32_t)__builtin_amdgcn_ds_permute(
-            (int)((can_help ? hrank : nh + (lane - hrank)) << 2), (int)lane);
         const bool gives = can_give && grank < cnt;
         const bool helps = can_help && hrank < cnt;
         const uint32_t my_giver = lane_read(helps ? hrank : lane, giver_k);
+#ifdef RTOW_DONATE_R2
+        const uint32_t helper_k = (uint32_t)__builtin_amdgcn_ds_permute(
+            (int)((can_help ? hrank : nh + (lane - hrank)) << 2), (int)lane);
         const uint32_t my_helper = lane_read(gives ? grank : lane, helper_k);
+#endif
         const uint32_t gsrc = helps ? my_giver : lane;
         const uint32_t o_j = lane_read(gsrc, j), o_gi = lane_read(gsrc, gi);
         const uint32_t o_pixel = lane_read(gsrc, g.pixel), o_sample = lane_read(gsrc, g.sample);
         const uint32_t o_left = lane_read(gsrc, (uint32_t)s_left);
         if (gives) {
           s_left -= 1;
+#ifdef RTOW_DONATE_R2
           partners = (partners << 6) | my_helper;
+#endif
           ++n_out;
         }
         if (helps) {
