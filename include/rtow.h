@@ -259,13 +259,14 @@ int rtow_profile_collect(rtow_ctx *ctx, double *kernel_ms_sum, int32_t *launches
  * wave end times, [29..33] the finer regions, when the RTOW_STAMPS diagnostic kernel ran). */
 int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out48);
 
-/* Diagnostic only: the LEVELS a render of `cfg` is cut into on this context — pairs (first sample
- * index, sample count), one work item per pixel and level.  RTOW_F64_STRICT: one level per stream
- * (spp / nstreams samples, the reference's threads, src/render.cpp:151-166).  Fast builds: a schedule over
- * the same sample range that does not depend on nstreams — chunks of RTOW_SCHED_CHUNK (16) samples, then
- * chunks shrinking to single samples at the end of the launch (csrc/rtow_capi.cpp, make_schedule).
- * Returns the number of levels (writes at most `capacity_pairs` of them).  `ctx` may be NULL: the table
- * of a new context (pure host arithmetic, usable without a GPU). */
+/* Diagnostic only: the LEVELS a render of `cfg` is cut into on this context — pairs (first sample index,
+ * sample count), one work item per pixel and level.  RTOW_F64_STRICT: one level per stream (spp / nstreams
+ * samples, the reference's threads, src/render.cpp:151-166), summed in stream order like the reference.  Fast
+ * builds: the same samples in levels of ONE length that does not depend on nstreams — the divisor of the sample
+ * range nearest RTOW_SCHED_CHUNK (10) — so that Config::nthreads keeps its arithmetic meaning without setting
+ * the size of a work item (csrc/rtow_capi.cpp, level_plan).  Returns the number of levels (writes at most
+ * `capacity_pairs` of them).  `ctx` may be NULL: the table of a new context (pure host arithmetic, usable
+ * without a GPU). */
 int rtow_debug_schedule(rtow_ctx *ctx, const rtow_config_t *cfg, uint32_t *out_pairs, int32_t capacity_pairs);
 
 /* Diagnostic only: copies a resident scene image to the host (which: 0 BVH image, 1 grid image,

@@ -751,3 +751,52 @@ def test_fast_build_image_does_not_depend_on_nstreams(ctx):
     half = ctx.render(scene, rtow.make_config(240, 160, 48, 4, 50, seed=5, precision=rtow.F64_FAST, stream_first=0,
                                                stream_count=2))[0]
     assert np.abs(half - full).mean() / 48 > 1e-3  # (really half the samples)
+
+
+def test_rtow_render_uploads_only_what_its_kernel_reads(ctx):
+    """rtow_render / rtow_render_rgb8 know their config and build only the structures its kernel reads (the cover
+    scene through the grid kernel: no BVH image, no binary32 images).  The image is the one a full upload gives;
+    a later rtow_render_device that needs a structure the lean upload left out is refused (not a wrong image)
+    until rtow_scene_upload — which builds everything — has run."""
+    import torch
+
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    cfg = rtow.make_config(120, 80, 8, 2, 50, seed=3, precision=rtow.F64_STRICT)
+    c = rtow.Context(0)
+    try:
+        c.upload(scene)
+        full_bi = c.build_info()
+        assert full_bi.bvh_image_bytes > 0 and full_bi.grid_image_bytes > 0
+        out = torch.zeros((80, 120, 3), dtype=torch.float64, device="cuda:0")
+        c.render_device(cfg, out.data_ptr(), 0, True)
+        torch.cuda.synchronize()
+        want = out.cpu().numpy()
+        img, st = c.render(scene, cfg)  # lean: the grid image only
+        assert np.array_equal(img, want) and st.kernel_used == rtow.KERNEL_GRID
+        lean_bi = c.build_info()
+        assert lean_bi.bvh_image_bytes == 0 and lean_bi.grid_image_bytes == full_bi.grid_image_bytes
+        bvh_cfg = rtow.make_config(120, 80, 8, 2, 50, seed=3, precision=rtow.F64_STRICT, kernel=rtow.KERNEL_BVH)
+        with pytest.raises(rtow.RtowError, match="rtow_scene_upload"):
+            c.render_device(bvh_cfg, out.data_ptr(), 0, True)
+        f32_cfg = rtow.make_config(120, 80, 8, 2, 50, seed=3, precision=rtow.F32)
+        with pytest.raises(rtow.RtowError):
+            c.render_device(f32_cfg, out.data_ptr(), 0, True)
+        via_bvh, _ = c.render(scene, bvh_cfg)  # rtow_render builds what THIS config needs
+        assert np.array_equal(via_bvh, want)
+        c.render(scene, f32_cfg)
+        c.upload(scene)
+        c.render_device(bvh_cfg, out.data_ptr(), 0, True)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        # the 8-bit entry point: write_color fused into the reduce kernel, bytes of the reference's PPM
+        import ctypes as C2
+        rgb8 = np.zeros((80, 120, 3), dtype=np.uint8)
+        L = rtow.lib()
+        L.rtow_render_rgb8.argtypes = [C2.c_void_p, C2.POINTER(rtow.Scene), C2.POINTER(rtow.Config), C2.c_void_p,
+                                       C2.POINTER(rtow.Stats)]
+        rtow.check(L.rtow_render_rgb8(c._h, C2.byref(scene.c), C2.byref(cfg), rgb8.ctypes.data_as(C2.c_void_p), None))
+        text = rtow.ppm_text(want, 120, 80, 8).split(b"\n")[3:]
+        ref8 = np.array([int(v) for line in text if line for v in line.split()], dtype=np.uint8).reshape(80, 120, 3)
+        assert np.array_equal(rgb8, ref8)
+    finally:
+        c.close()
