@@ -344,6 +344,11 @@ int rtow_host_ppm(const double *rgb_sums, int32_t width, int32_t height, int32_t
                   char **out_text, uint64_t *out_len);
 void rtow_host_free(void *p);
 
+/* The reference's own bounding-volume tree (src/render.cpp:73-110) over a flattened scene, as RTOW_KERNEL_REFTREE
+ * walks it, built on the host (no GPU): node count, depth and the reference's "Total BVH stupid volume"
+ * diagnostic (src/render.cpp:36-50,148). */
+int rtow_host_reftree_info(const rtow_scene_t *scene, int32_t *n_nodes, int32_t *depth, double *stupid_volume);
+
 #ifdef __cplusplus
 }
 #endif

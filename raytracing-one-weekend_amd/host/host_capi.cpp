@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/rtow.h"
+#include "../csrc/rtow_reftree.h"
 #include "scene_rng.h"
 #include "render.h"
 
@@ -114,5 +115,21 @@ int rtow_host_ppm(const double *rgb_sums, int32_t width, int32_t height, int32_t
 }
 
 void rtow_host_free(void *p) { std::free(p); }
+
+// The reference's own tree over a flattened scene (csrc/rtow_reftree.h — what RTOW_KERNEL_REFTREE walks), built
+// on the host without a GPU: node count, depth and the reference's "Total BVH stupid volume" diagnostic.
+int rtow_host_reftree_info(const rtow_scene_t *scene, int32_t *n_nodes, int32_t *depth, double *stupid_volume) {
+  if (!scene || scene->n_prims <= 0) return RTOW_EINVAL;
+  try {
+    rtow::RefTree t;
+    rtow::build_reftree(scene, t);
+    if (n_nodes) *n_nodes = t.n_nodes;
+    if (depth) *depth = t.depth;
+    if (stupid_volume) *stupid_volume = t.stupid_volume;
+    return t.ok ? RTOW_OK : RTOW_EINVAL;
+  } catch (...) {
+    return RTOW_ENOMEM;
+  }
+}
 
 }  // extern "C"

@@ -106,7 +106,7 @@ EXPORTS = [
     "rtow_ctx_set_builder", "rtow_build_info", "rtow_debug_image", "rtow_render_multi",
     "rtow_debug_schedule", "rtow_host_scene_cover_model", "rtow_host_scene_obj_model",
     "rtow_multi_create", "rtow_multi_set_builder", "rtow_multi_upload", "rtow_multi_build_info",
-    "rtow_multi_render", "rtow_multi_destroy",
+    "rtow_multi_render", "rtow_multi_destroy", "rtow_host_reftree_info",
 ]
 
 
@@ -166,6 +166,9 @@ def lib():
     L.rtow_render_multi.argtypes = [C.c_int32, _pi, C.POINTER(Scene), C.POINTER(Config), _pd, C.POINTER(Stats),
                                     C.c_int32]
     L.rtow_debug_image.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    if hasattr(L, "rtow_host_reftree_info"):
+        L.rtow_host_reftree_info.argtypes = [C.POINTER(Scene), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_double)]
     if hasattr(L, "rtow_multi_create"):
         L.rtow_multi_create.argtypes = [C.c_int32, _pi, C.c_int32, C.POINTER(C.c_void_p)]
         L.rtow_multi_set_builder.argtypes = [C.c_void_p, C.c_int32]

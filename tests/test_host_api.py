@@ -231,3 +231,28 @@ def test_fast_build_schedule_properties(spp, ns, monkeypatch):
         assert all(c == ps[0][1] for _, c in ps) and ps[0][0] % ps[0][1] == 0
     monkeypatch.setenv("RTOW_SCHED_CHUNK", "0")  # off: the strict build's levels
     assert _schedule(rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST)) == _schedule(strict)
+
+
+@pytest.mark.parametrize("which", ["cover", "moving", "suzanne", "tiny"])
+def test_product_reference_tree_builder_matches_the_oracles_tree(which):
+    """csrc/rtow_reftree.h (the product's restatement of the reference's BVH build, src/render.cpp:73-110, which
+    RTOW_KERNEL_REFTREE walks on the device) against the oracle's restatement of the same build, without a GPU:
+    node count and the reference's "Total BVH stupid volume" diagnostic — a sum over every node's box, so it
+    sees the boxes (float-rounded triangle corners, origin-unioned leaves), the split axes and the sort order —
+    and against the values SURVEY.md §8c records from the reference itself (2150.93 / 34.6011)."""
+    if which == "suzanne":
+        scene = rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9)
+        oscene, cfg, survey = orc.OrcScene.obj(GOLDEN / "suzanne.obj", 16 / 9), rtow.make_config(8, 4, 1, 1, 2), 34.6011
+    else:
+        n, moving = (0, False) if which == "tiny" else (11, which == "moving")
+        scene = rtow.HostScene.cover(n, 1.5, moving)
+        oscene, cfg = orc.OrcScene.cover(n, 1.5, moving), rtow.make_config(8, 4, 1, 1, 2)
+        survey = 2150.93 if which == "cover" else None
+    nodes, depth, vol = C.c_int32(), C.c_int32(), C.c_double()
+    assert rtow.lib().rtow_host_reftree_info(C.byref(scene.c), C.byref(nodes), C.byref(depth), C.byref(vol)) == 0
+    _, ost = orc.render(oscene, cfg, orc.RNG_MT19937, nthreads=1)  # (the oracle builds the reference's tree per render)
+    assert nodes.value == ost.bvh_nodes
+    assert vol.value == ost.bvh_stupid_volume  # the same operations in the same order: equal, not close
+    if survey is not None:
+        assert float("%.6g" % vol.value) == survey
+    assert 0 <= depth.value < 48
