@@ -801,6 +801,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     if constexpr (STAMPS) {
       stamps.trips += 1;
       if (t_empty != 0ull) trips_after_empty += 1;
+      stamps.tail = t_empty != 0ull;
     }
     // ---- one ray segment: closest hit --------------------------------------------
     if constexpr (KERNEL != 3 && KERNEL != 4) {
@@ -902,6 +903,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         }
       }
       for (int r = 0; r < RG_COUNT; ++r) atomicAdd(&P.counters[8 + r], stamps.t[r]);
+      for (int r = 0; r < RG_COUNT; ++r) atomicAdd(&P.counters[29 + r], stamps.tt[r]);  // after queue-empty only
+      atomicAdd(&P.counters[37], trips_after_empty);
+      atomicAdd(&P.counters[38], tend - t_empty);
       for (int r = 0; r < RG_COUNT; ++r) atomicAdd(&P.counters[23 + r], stamps.lt[r]);
       atomicAdd(&P.counters[34], stamps.step_lanes);
       atomicAdd(&P.counters[44], stamps.blocks);

@@ -10,6 +10,8 @@ template <bool ON>
 struct Stamps {
   unsigned long long t[RG_COUNT] = {0, 0, 0, 0, 0};
   unsigned long long last = 0;
+  unsigned long long tt[RG_COUNT] = {0, 0, 0, 0, 0};    // the same cycles, only for the trips after this wave found the queue empty
+  bool tail = false;
   unsigned long long lt[RG_COUNT] = {0, 0, 0, 0, 0};    // the same, weighted by the lanes the region worked for
   unsigned long long iters = 0, trips = 0, phases = 0;  // wave-level loop counts
   unsigned long long blocks = 0, block_lanes = 0;       // Philox block evaluations of the new-ray stage / lanes in its rejection trips
@@ -21,6 +23,7 @@ struct Stamps {
     if constexpr (ON) {
       const unsigned long long n = now();
       t[region] += n - last;
+      if (tail) tt[region] += n - last;
       last = n;
     }
   }
@@ -28,6 +31,7 @@ struct Stamps {
     if constexpr (ON) {
       const unsigned long long n = now();
       t[region] += n - last;
+      if (tail) tt[region] += n - last;
       lt[region] += (n - last) * (unsigned long long)__popcll(lanes);
       last = n;
     }

@@ -24,8 +24,14 @@ print(which, "kernel_ms(with stamps)", round(st.kernel_ms, 3), "Msamples/s", rou
       "segments", st.segments, "node/seg", round(st.node_tests / st.segments, 2), "prim/seg", round(st.prim_tests / st.segments, 2))
 for i, n in enumerate(names):
     print(f"{n:12s} {out[8+i]/tot*100:5.1f}%")
-for i, n in enumerate(["large list", "walk set-up", "hit record", "rejection", "sky+unwind"]):
-    print(f"{n:12s} {out[29+i]/tot*100:5.1f}%   (split out of walk-steps / shade)")
+ttot = sum(out[29:34]) or 1
+print("after a wave found the queue empty: shader-clock cycles per trip by region (s_memtime), and the same in the whole launch:")
+for i, n in enumerate(names):
+    print(f"  {n:12s} {out[29+i]/max(out[37],1):9.0f} cycles/trip ({out[29+i]/ttot*100:5.1f}%)   whole launch {out[8+i]/max(trips,1):9.0f} cycles/trip" if False else "", end="")
+trips_all = out[14] or 1
+for i, n in enumerate(names):
+    print(f"  {n:12s} tail {out[29+i]/max(out[37],1):9.0f} cycles/trip ({out[29+i]/ttot*100:5.1f}%)   launch {out[8+i]/trips_all:9.0f} cycles/trip")
+print(f"  trips after queue-empty, all waves: {int(out[37])}; wall time after queue-empty per such trip: {out[38]/max(out[37],1)/100:.2f} us")
 print("lanes a region worked for (of 64; entry masks, so an upper bound on what its instructions saw):")
 for i, n in enumerate(names):
     if out[8 + i]:
