@@ -88,6 +88,11 @@ def test_random_scene_all_kernels_and_builders_match_the_oracle(ctx, shape):
                     assert st.kernel_used == rtow.KERNEL_BVH4
                 assert st.segments == ost.segments, (kernel, st.kernel_used)
                 assert np.array_equal(img, ref), (kernel, st.kernel_used, int((img != ref).sum()))
+            # the opt-in kernel that walks the reference's own tree: the oracle's walk, test for test
+            rimg, rst = c.render(scene, rtow.make_config(72, 48, 4, 2, 12, seed=shape[0] + 3, precision=rtow.F64_STRICT,
+                                                         kernel=rtow.KERNEL_REFTREE))
+            assert rst.kernel_used == rtow.KERNEL_REFTREE and np.array_equal(rimg, ref) and rst.segments == ost.segments
+            assert rst.node_tests == ost.node_tests and rst.prim_tests == ost.prim_tests
             # the fast and f32 builds: finite, close, and the same from both builders
             fa, _ = c.render(scene, rtow.make_config(72, 48, 16, 4, 12, seed=5, precision=rtow.F64_FAST))
             f3, _ = c.render(scene, rtow.make_config(72, 48, 16, 4, 12, seed=5, precision=rtow.F32))

@@ -542,6 +542,20 @@ def test_stream_ranges_are_chunked_automatically_and_bit_identical(ctx, monkeypa
     assert sp.samples == sw.samples and sp.segments == sw.segments
     ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
     assert np.array_equal(parts, ref)
+    # the fast build's levels (here 120 samples in 12 levels of 10, whatever nstreams is) in ranges of 4: the same
+    fcfg = rtow.make_config(120, 80, 120, 3, 50, seed=2, precision=rtow.F64_FAST)
+    fwhole, fw = ctx.render(scene, fcfg)
+    small = rtow.Context(0)
+    fparts, fp = small.render(scene, fcfg)
+    rgb8a, rgb8b = np.zeros((80, 120, 3), np.uint8), np.zeros((80, 120, 3), np.uint8)
+    L = rtow.lib()
+    L.rtow_render_rgb8.argtypes = [C.c_void_p, C.POINTER(rtow.Scene), C.POINTER(rtow.Config), C.c_void_p, C.POINTER(rtow.Stats)]
+    # (the 8-bit entry point: several launches, so write_color runs as its own kernel instead of inside the reduce)
+    rtow.check(L.rtow_render_rgb8(small._h, C.byref(scene.c), C.byref(fcfg), rgb8b.ctypes.data_as(C.c_void_p), None))
+    rtow.check(L.rtow_render_rgb8(ctx._h, C.byref(scene.c), C.byref(fcfg), rgb8a.ctypes.data_as(C.c_void_p), None))
+    small.close()
+    assert np.array_equal(fwhole, fparts) and fp.samples == fw.samples == 120 * 80 * 120 and fp.segments == fw.segments
+    assert np.array_equal(rgb8a, rgb8b)
 
 
 def test_rtweekend_gpus_flag_partitions_like_one_device(ctx):
