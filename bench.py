@@ -105,7 +105,8 @@ def parse():
                     help="N=1: skip the lines for nstreams = 4 (the reference's default thread count)")
     ap.add_argument("--precision", choices=["fast", "strict", "f32"], default="fast",
                     help="fast/strict: binary64 (the metric's arithmetic); f32: the preview build, never the headline")
-    ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid", "bvh4"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "brute", "bvh", "grid", "bvh4", "reftree"], default="auto",
+                    help="reftree: the reference's own tree and box test (needs --precision strict; an exactness mode)")
     ap.add_argument("--moving", action="store_true", help="same as --workload moving")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", choices=["tiles", "samples"], default="tiles",
@@ -245,7 +246,8 @@ def prim_model(scene):
 KERNEL_NAMES = {1: "stream (every lane tests every primitive, scalar-load broadcast)",
                 2: "bvh (per-lane walk of the scene image in LDS, or in L2 when it does not fit)",
                 3: "grid (per-lane 3D-DDA over the LDS scene image + large-primitive list)",
-                4: "bvh4 (per-lane ordered walk of a 4-wide BVH, stack in LDS; image or its top levels in LDS)"}
+                4: "bvh4 (per-lane ordered walk of a 4-wide BVH, stack in LDS; image or its top levels in LDS)",
+                5: "reftree (the reference's own median-split tree, left before right, f64 Aabb::hit; strict build)"}
 
 
 def kernel_source_sha():
@@ -397,6 +399,18 @@ def other_config(name, a, dev, precision, steps, stress=False):
     return line
 
 
+def samples_per_item(ctx, cfg):
+    """Length of a work item of this render (rtow_debug_schedule): spp / nstreams in the strict build, the
+    divisor of the sample range nearest the aimed-at length in the fast builds (10; 16 for a mesh)."""
+    import ctypes as C
+    L = rtow.lib()
+    if not hasattr(L, "rtow_debug_schedule"):
+        return cfg.samples_per_pixel // cfg.nstreams
+    pairs = (C.c_uint32 * 8)()
+    n = L.rtow_debug_schedule(ctx._h, C.byref(cfg), pairs, 4)
+    return int(pairs[1]) if n > 0 else 0
+
+
 def main():
     a = parse()
     if a.moving:
@@ -440,7 +454,7 @@ def main():
         tile_rows = int(os.environ["RTOW_BENCH_TILE_ROWS"])
     precision = {"fast": rtow.F64_FAST, "strict": rtow.F64_STRICT, "f32": rtow.F32}[a.precision]
     kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID,
-              "bvh4": rtow.KERNEL_BVH4}[a.kernel]
+              "bvh4": rtow.KERNEL_BVH4, "reftree": rtow.KERNEL_REFTREE}[a.kernel]
     split_samples = a.split == "samples" and world > 1
     if split_samples:
         s_first, s_count = tiles.stream_range(nstreams, world, rank)
@@ -480,6 +494,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     st0 = step(want_stats=True)  # also sizes the workspace (allocation outside the timed region)
+    spi = samples_per_item(ctx, cfg)
     for _ in range(max(a.warmup - 1, 0)):
         step()
     fence()
@@ -534,7 +549,7 @@ def main():
                                 f", {tile_rows}-row strips over {world} GPUs + 1 RCCL gather")),
                 "baseline_config": base_cfg if (world == 1 and spp == spp0) else
                                    ("configs[2]" if (spp == 500 and kind == "cover") else "custom"),
-                "spp_effective": spp_eff, "samples_per_item": spp // nstreams, "nstreams": nstreams,
+                "spp_effective": spp_eff, "samples_per_item": spi, "nstreams": nstreams,
                 "seed": SEED, "precision": a.precision,
                 "kernel": KERNEL_NAMES[st0.kernel_used],
                 "segments_per_sample": round(segments / samples, 4),

@@ -217,7 +217,8 @@ typedef struct rtow_build_info_t {
   /* RTOW_KERNEL_REFTREE (built at the first render that asks for it; 0 before): nodes of the reference's
    * tree and its "Total BVH stupid volume" diagnostic (src/render.cpp:36-50,148) */
   int32_t ref_tree_nodes;
-  int32_t pad_;
+  int32_t bvh4_node_bytes;  /* 128: binary32 planes (image staged in LDS whole); 64: binary16 planes in the mesh's own
+                               frame (bigger meshes, nodes read from L2); 0 = no 4-wide image */
   double ref_tree_stupid_volume;
   double ref_tree_build_ms;
 } rtow_build_info_t;
@@ -263,8 +264,8 @@ int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out48);
  * sample count), one work item per pixel and level.  RTOW_F64_STRICT: one level per stream (spp / nstreams
  * samples, the reference's threads, src/render.cpp:151-166), summed in stream order like the reference.  Fast
  * builds: the same samples in levels of ONE length that does not depend on nstreams — the divisor of the sample
- * range nearest RTOW_SCHED_CHUNK (10) — so that Config::nthreads keeps its arithmetic meaning without setting
- * the size of a work item (csrc/rtow_capi.cpp, level_plan).  Returns the number of levels (writes at most
+ * range nearest RTOW_SCHED_CHUNK (10; 16 when the resident scene is a triangle mesh) — so that Config::nthreads
+ * keeps its arithmetic meaning without setting the size of a work item (csrc/rtow_capi.cpp, level_plan).  Returns the number of levels (writes at most
  * `capacity_pairs` of them).  `ctx` may be NULL: the table of a new context (pure host arithmetic, usable
  * without a GPU). */
 int rtow_debug_schedule(rtow_ctx *ctx, const rtow_config_t *cfg, uint32_t *out_pairs, int32_t capacity_pairs);

@@ -257,6 +257,8 @@ struct Knobs {
                                   //   (default 8), else the entries per lane beside the staged top of the tree (default 24)
   int sched_chunk = 10;           // RTOW_SCHED_CHUNK: fast builds: samples per work item aimed at (0 = one item per stream and
                                   //   pixel, like the strict build).  5 / 10 / 20 / 25: 10.88 / 11.18 / 10.22 / 9.55 Gsamples/s on C2
+  int sched_chunk_mesh = 16;      //   ... for a scene of triangles only (its walks are longer and resumable: fewer, longer items;
+                                  //   4 / 8 / 16 / 32 samples: 4.60 / 4.64 / 4.69 / 4.68 Gsamples/s on C4, 2.29 / 2.30 / 2.32 / 2.32 on C5)
   void read() {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
     auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
@@ -298,6 +300,7 @@ struct Knobs {
     }
     bvh4_stack_k = std::min(std::max(geti("RTOW_BVH4_STACK_K", 0), 0), 64);
     sched_chunk = std::min(std::max(geti("RTOW_SCHED_CHUNK", 10), 0), 4096);
+    sched_chunk_mesh = std::min(std::max(geti("RTOW_SCHED_CHUNK", 16), 0), 4096);
   }
 };
 
@@ -355,6 +358,9 @@ struct rtow_ctx {
   // pinned host mirror of the counters for stats
   unsigned long long *h_counters = nullptr;
 };
+
+// BVH4: stack entries per lane (4 B x 1024 lanes each) an image staged whole must leave room for (RTOW_BVH4_STACK_K)
+static uint32_t bvh4_min_stack(const rtow_ctx *c) { return c->knobs.bvh4_stack_k > 0 ? (uint32_t)c->knobs.bvh4_stack_k : 8u; }
 
 extern "C" {
 
@@ -573,6 +579,7 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
   c->have_bvh4 = false;
   c->build_info.bvh4_nodes = 0;
   c->build_info.bvh4_image_bytes = 0;
+  c->build_info.bvh4_node_bytes = 0;
   if (need & kNeedBvh) {
   if (c->builder == RTOW_BUILDER_DEVICE_LBVH) {
     // the tree is built in HBM from the record arrays just uploaded; the host only lays out
@@ -628,6 +635,10 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
       if (!prim_order.empty()) {  // the same SAH tree, collapsed (leaves of at most 4 triangles)
         bvh.prim = prim_order;
         rtow::make_bvh4_image(bvh, tri, pmat, mats_bytes, s->camera.origin, img4);
+        // an image that LDS cannot hold whole is read from L2 below the top of its tree: 64-byte nodes with
+        // binary16 planes (4 loads per node instead of 7; rtow_bvh4.h)
+        if (img4.ok && img4.blob.size() + bvh4_min_stack(c) * 4u * 1024u > kLdsLimit)
+          rtow::make_bvh4_image(bvh, tri, pmat, mats_bytes, s->camera.origin, img4, /*half=*/true);
       }
       if (img4.ok) {
         if (!rtow::validate_bvh4_image(img4, (size_t)nt))
@@ -640,8 +651,14 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
         c->ds.b4_off_tri = img4.off_tri;
         c->ds.b4_off_pmat = img4.off_pmat;
         c->ds.b4_off_mats = img4.off_mats;
+        c->ds.b4_half = img4.half ? 1u : 0u;
+        for (int k = 0; k < 3; ++k) {
+          c->ds.b4_c[k] = img4.map_c[k];
+          c->ds.b4_is[k] = (float)(1.0 / img4.map_s[k]);
+        }
         c->build_info.bvh4_nodes = img4.n_nodes;
         c->build_info.bvh4_image_bytes = (int32_t)img4.blob.size();
+        c->build_info.bvh4_node_bytes = (int32_t)img4.node_bytes();
       }
     }
   }
@@ -889,6 +906,11 @@ int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t cap
 // drop-in caller with the reference's default of 4 threads (25 or 125 samples per stream) runs the items the
 // bench runs.  The sum of a pixel is then the fixed-order sum of its level sums; the image is a pure function
 // of (scene, config, seed) and of nothing else.
+// (the item length aimed at depends on the class of the resident scene, not on anything else)
+static int sched_chunk_for(const rtow_ctx *c) {
+  const bool mesh = c->have_scene && c->ds.n_tri > 0 && c->ds.n_sph == 0 && c->ds.n_mov == 0;
+  return mesh ? c->knobs.sched_chunk_mesh : c->knobs.sched_chunk;
+}
 struct LevelPlan {
   int spt;    // samples per level
   int first;  // index of the first level: its first sample is first * spt
@@ -932,7 +954,7 @@ static int impl_debug_schedule(rtow_ctx *c, const rtow_config_t *cfg, uint32_t *
   if (rc) return rc;
   Knobs defaults;  // ctx NULL: the defaults of a new context (pure host arithmetic, usable without a GPU)
   if (!c) defaults.read();
-  const LevelPlan p = level_plan(cfg, (c ? c->knobs : defaults).sched_chunk);
+  const LevelPlan p = level_plan(cfg, c ? sched_chunk_for(c) : defaults.sched_chunk);
   for (int i = 0; i < p.count && i < capacity_pairs && out; ++i) {
     out[2 * i] = (uint32_t)(p.first + i) * (uint32_t)p.spt;
     out[2 * i + 1] = (uint32_t)p.spt;
@@ -958,7 +980,7 @@ static int impl_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb
   const int streams_now = cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams;
   if ((unsigned long long)spt * (unsigned long long)(cfg->stream_first + streams_now) > 0xffffffffULL)
     return fail(RTOW_EINVAL, "sample index beyond 32 bits");
-  const LevelPlan plan = level_plan(cfg, c->knobs.sched_chunk);
+  const LevelPlan plan = level_plan(cfg, sched_chunk_for(c));
   const int n_levels = plan.count;
   // Large sample counts: the per-level partial sums (24 B per pixel and level) are bounded by tracing the
   // levels in ranges that accumulate onto d_rgb_sums — bit-identical to one launch (the reduce kernel adds
@@ -1073,11 +1095,14 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
     const uint32_t per_entry = 4u * (uint32_t)block;
     stack_bound = 3 * c->bvh4_depth + 1;
     uint32_t K, staged, aux_src = scene.blob4_bytes, aux_bytes = 0u;
-    const uint32_t min_k = c->knobs.bvh4_stack_k > 0 ? (uint32_t)c->knobs.bvh4_stack_k : 8u;  // RTOW_BVH4_STACK_K
-    if (scene.blob4_bytes + min_k * per_entry <= kLdsLimit) {
+    const uint32_t min_k = bvh4_min_stack(c);
+    const uint32_t node_bytes = scene.b4_half ? rtow::kBvh4HalfNodeBytes : rtow::kBvh4NodeBytes;
+    if (!scene.b4_half && scene.blob4_bytes + min_k * per_entry <= kLdsLimit) {
       staged = scene.blob4_bytes;
       K = std::min<uint32_t>((kLdsLimit - staged) / per_entry, 32u);
       if (c->knobs.bvh4_stack_k > 0) K = std::min<uint32_t>(K, (uint32_t)c->knobs.bvh4_stack_k);  // (experiments: fewer)
+    } else if (!scene.b4_half) {
+      return fail(RTOW_EINVAL, "internal error: a 4-wide image with binary32 nodes must fit LDS whole");
     } else {
       // (stack entries 6 / 8 / 10 / 12 / 16 / 24 on the 96.8k-triangle mesh: 2.07 / 2.12 / 2.12 / 2.11 / 2.10 / 2.10
       // Gsamples/s — what the stack does not need holds 128-byte nodes)
@@ -1090,8 +1115,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
       else if (scene.blob4_bytes - scene.b4_off_mats <= aux_max)
         aux_src = scene.b4_off_mats;
       aux_bytes = scene.blob4_bytes - aux_src;
-      staged = std::min<uint32_t>((kLdsLimit - K * per_entry - aux_bytes) / rtow::kBvh4NodeBytes * rtow::kBvh4NodeBytes,
-                                  scene.b4_off_tri);
+      staged = std::min<uint32_t>((kLdsLimit - K * per_entry - aux_bytes) / node_bytes * node_bytes, scene.b4_off_tri);
     }
     K = std::min<uint32_t>(K, (uint32_t)stack_bound);
     scene.b4_lds_limit = staged;

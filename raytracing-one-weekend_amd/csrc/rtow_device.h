@@ -57,17 +57,23 @@ struct DevScene {
   uint32_t gblob_bytes;
   uint32_t g_off_cells, g_off_ids, g_off_sph, g_off_mov, g_off_tri, g_off_pmat, g_off_mats;
   uint32_t g_off_sph32, g_off_mov32;
-  // scene image for the BVH4 kernel (rtow_bvh4.h; triangle meshes): 128-byte nodes in breadth-first
+  // scene image for the BVH4 kernel (rtow_bvh4.h; triangle meshes): 128- or 64-byte nodes in breadth-first
   // order, then triangle records in leaf order, material index per record, materials
   const unsigned char *blob4;
   uint32_t blob4_bytes;
   uint32_t b4_off_tri, b4_off_pmat, b4_off_mats;
-  uint32_t b4_lds_limit;   // bytes of the image staged in LDS: all of it, or a 128-byte-aligned prefix of the nodes
+  uint32_t b4_lds_limit;   // bytes of the image staged in LDS: all of it, or a node-aligned prefix of the nodes
   // when only the top of the tree is staged: the END of the image from byte b4_aux_src on (the materials, and the
   // material indices if they are small) is staged too, at LDS offset b4_aux_lds — shading reads them after every hit
   uint32_t b4_aux_src, b4_aux_lds;
   uint32_t b4_stack_base;  // LDS byte offset of the traversal stack ([entry][lane of the workgroup], 4 B each)
   uint32_t b4_stack_k;     // entries per lane in LDS; deeper entries go to TraceParams::spill
+  // an image that is not staged whole has 64-byte nodes with binary16 planes (b4_half; rtow_bvh4.h) in the mesh's
+  // own frame: plane' = (plane - b4_c) * s per axis; the ray takes (o - b4_c) and 1/(d s) so that t comes out
+  // unchanged.  b4_is = 1/s.
+  double b4_c[3];
+  float b4_is[3];
+  uint32_t b4_half;
   // the reference's own tree (rtow_reftree.h; kernel RTOW_KERNEL_REFTREE): [nodes x 64 B][ids], in global memory
   const unsigned char *rtree;
   uint32_t rt_off_ids;

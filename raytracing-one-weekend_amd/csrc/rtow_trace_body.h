@@ -56,6 +56,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "rtow_device.h"
 
@@ -975,7 +976,7 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
                        : launch_one<3, false, false>(p, grid, block, 0, st);
     case 4:
     case 4 + 16: {
-      const bool full = p.sc.b4_lds_limit == p.sc.blob4_bytes, stamps = kernel == 4 + 16;
+      const bool full = p.sc.b4_half == 0u, stamps = kernel == 4 + 16;  // (binary32 nodes <=> staged whole)
       if (p.b4_trips)  // the trip-structured form (default); RTOW_BVH4_SM selects the state machine
         return full ? (stamps ? launch_one<4, true, true>(p, grid, block, lds_bytes, st)
                               : launch_one<4, true, false>(p, grid, block, lds_bytes, st))

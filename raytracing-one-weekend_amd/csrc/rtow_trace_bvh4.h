@@ -7,6 +7,8 @@
 //     axis (lo.x[4] hi.x[4] ...), so a lane reads the near planes of all four children with one
 //     16-byte load at an address chosen by the sign of its ray direction, and the far planes at
 //     that address ^ 16: the slab test is 6 fma + max3 + min3 per child, no min/max per plane.
+//     (Half nodes: 8-byte reads from LDS the same way; from L2 one 16-byte load per axis — both halves —
+//     and four selects, because there each load instruction costs the address unit 16 cycles whatever its size.)
 //   * The nearest hit child is visited next, the other hit children go to the stack with their entry
 //     distance (11 bits of it, rounded down), so that a popped entry beyond the closest hit so far is
 //     dropped without touching its node.  Stack entry: [tnear >> 20 : 11][ref21 : 21] (rtow_bvh4.h).
@@ -19,10 +21,8 @@
 //     is staged whole, a big one has the top of its tree (breadth-first node order) in LDS.
 // Termination: child links only point to later nodes (validated at upload), so every node is entered
 // at most once per ray; every loop trip either pops, enters a node, queues a leaf or runs the leaf phase.
-#ifndef RTOW_BVH4_NODE_BYTES
-#define RTOW_BVH4_NODE_BYTES 128
-#endif
-constexpr uint32_t kBvh4NodeBytes = RTOW_BVH4_NODE_BYTES;  // rtow_bvh4.h
+// Node format (rtow_bvh4.h): an image staged whole (FULL) has 128-byte nodes with binary32 planes; a bigger one,
+// whose nodes are read from L2 below the staged top, has 64-byte nodes with binary16 planes in the mesh's own frame.
 constexpr uint32_t kRefNone = 0x1fffffu;   // rtow_bvh4.h
 constexpr uint32_t kRefLeaf = 1u << 20;
 constexpr uint32_t kRefPop = 0x1ffffeu;    // traversal state only: take the next entry from the stack
@@ -33,6 +33,7 @@ constexpr uint32_t kRefPop = 0x1ffffeu;    // traversal state only: take the nex
 typedef float vf4 __attribute__((ext_vector_type(4)));      // native vectors: HIP's float4 class cannot be
 typedef uint32_t vu4 __attribute__((ext_vector_type(4)));   // read through an address-space pointer
 typedef double vd2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vh4 __attribute__((ext_vector_type(4)));   // four binary16 planes: the operands of v_fma_mix_f32
 #define RTOW_AS_LDS __attribute__((address_space(3)))
 #define RTOW_AS_GLB __attribute__((address_space(1)))
 template <class T>
@@ -85,11 +86,20 @@ struct Bvh4Ray {
   float ix, iy, iz, oix, oiy, oiz;  // 1/d (huge if d is 0) and o/d: t(plane) = plane * ix - oix
   uint32_t nxo, nyo, nzo;           // where this ray finds the NEAR planes of a node (the far planes: address ^ 16)
 };
-__device__ __forceinline__ Bvh4Ray bvh4_ray(V3 o, V3 d) {
+template <bool FULL>
+__device__ __forceinline__ Bvh4Ray bvh4_ray(const DevScene &sc, V3 o, V3 d) {
   Bvh4Ray r;
   r.ix = safe_inv((float)d.x), r.iy = safe_inv((float)d.y), r.iz = safe_inv((float)d.z);
-  r.oix = (float)o.x * r.ix, r.oiy = (float)o.y * r.iy, r.oiz = (float)o.z * r.iz;
-  r.nxo = r.ix < 0.0f ? 16u : 0u, r.nyo = r.iy < 0.0f ? 48u : 32u, r.nzo = r.iz < 0.0f ? 80u : 64u;
+  if constexpr (!FULL) {
+    // half nodes: planes are stored as (plane - c) * s, so t = plane' * (1 / (d s)) - (o - c) / d
+    r.oix = (float)(o.x - (real)sc.b4_c[0]) * r.ix, r.oiy = (float)(o.y - (real)sc.b4_c[1]) * r.iy,
+    r.oiz = (float)(o.z - (real)sc.b4_c[2]) * r.iz;
+    r.nxo = r.ix < 0.0f ? 8u : 0u, r.nyo = r.iy < 0.0f ? 24u : 16u, r.nzo = r.iz < 0.0f ? 40u : 32u;
+    r.ix *= sc.b4_is[0], r.iy *= sc.b4_is[1], r.iz *= sc.b4_is[2];
+  } else {
+    r.oix = (float)o.x * r.ix, r.oiy = (float)o.y * r.iy, r.oiz = (float)o.z * r.iz;
+    r.nxo = r.ix < 0.0f ? 16u : 0u, r.nyo = r.iy < 0.0f ? 48u : 32u, r.nzo = r.iz < 0.0f ? 80u : 64u;
+  }
   return r;
 }
 // This lane's traversal stack: LDS slot s at lds + s * kBvh4StackStride (workgroups are 1024 lanes); slots at or
@@ -138,26 +148,38 @@ __device__ __forceinline__ void bvh4_step(const Bvh4Reader<FULL> &im, const Trac
   }
   // (3) one node: four slab tests, nearest hit child next, the others to the stack
   if (cur < kRefLeaf) {
-    const uint32_t nb = cur * kBvh4NodeBytes;
-    vf4 nx, fx, ny, fy, nz, fz;
+    // binary32 planes (FULL), or binary16 planes whose near / far halves of an axis are 8 bytes apart; the fma
+    // below takes either as it is (v_fma_mix_f32: binary16 operand, binary32 arithmetic)
+    typedef typename std::conditional<FULL, vf4, vh4>::type planes_t;
+    constexpr uint32_t kFar = FULL ? 16u : 8u, kChild = FULL ? 96u : 48u;
+    const uint32_t nb = cur * (FULL ? 128u : 64u);
+    planes_t nx, fx, ny, fy, nz, fz;
     vu4 cw;
     if (FULL || nb < im.lds_limit) {
-      nx = lds_read<vf4>(nb + r.nxo), fx = lds_read<vf4>((nb + r.nxo) ^ 16u);
-      ny = lds_read<vf4>(nb + r.nyo), fy = lds_read<vf4>((nb + r.nyo) ^ 16u);
-      nz = lds_read<vf4>(nb + r.nzo), fz = lds_read<vf4>((nb + r.nzo) ^ 16u);
-      cw = lds_read<vu4>(nb + 96u);
-    } else {
-      nx = glb_read<vf4>(im.g, nb + r.nxo), fx = glb_read<vf4>(im.g, (nb + r.nxo) ^ 16u);
-      ny = glb_read<vf4>(im.g, nb + r.nyo), fy = glb_read<vf4>(im.g, (nb + r.nyo) ^ 16u);
-      nz = glb_read<vf4>(im.g, nb + r.nzo), fz = glb_read<vf4>(im.g, (nb + r.nzo) ^ 16u);
-      cw = glb_read<vu4>(im.g, nb + 96u);
+      nx = lds_read<planes_t>(nb + r.nxo), fx = lds_read<planes_t>((nb + r.nxo) ^ kFar);
+      ny = lds_read<planes_t>(nb + r.nyo), fy = lds_read<planes_t>((nb + r.nyo) ^ kFar);
+      nz = lds_read<planes_t>(nb + r.nzo), fz = lds_read<planes_t>((nb + r.nzo) ^ kFar);
+      cw = lds_read<vu4>(nb + kChild);
+    } else if constexpr (!FULL) {
+      // four 16-byte loads per node (the address path of the vector memory unit is what a big mesh waits for):
+      // both halves of an axis in one load, near / far chosen by selects
+      const vu4 ax = glb_read<vu4>(im.g, nb), ay = glb_read<vu4>(im.g, nb + 16u), az = glb_read<vu4>(im.g, nb + 32u);
+      cw = glb_read<vu4>(im.g, nb + kChild);
+      const bool sx = (r.nxo & 8u) != 0u, sy = (r.nyo & 8u) != 0u, sz = (r.nzo & 8u) != 0u;
+      typedef uint32_t vu2 __attribute__((ext_vector_type(2)));
+      const vu2 nxu = {sx ? ax.z : ax.x, sx ? ax.w : ax.y}, fxu = {sx ? ax.x : ax.z, sx ? ax.y : ax.w};
+      const vu2 nyu = {sy ? ay.z : ay.x, sy ? ay.w : ay.y}, fyu = {sy ? ay.x : ay.z, sy ? ay.y : ay.w};
+      const vu2 nzu = {sz ? az.z : az.x, sz ? az.w : az.y}, fzu = {sz ? az.x : az.z, sz ? az.y : az.w};
+      nx = __builtin_bit_cast(vh4, nxu), fx = __builtin_bit_cast(vh4, fxu);
+      ny = __builtin_bit_cast(vh4, nyu), fy = __builtin_bit_cast(vh4, fyu);
+      nz = __builtin_bit_cast(vh4, nzu), fz = __builtin_bit_cast(vh4, fzu);
     }
     ++nnode;
 #define RTOW_SLAB(c, slot)                                                                                             \
-  const float tn##slot =                                                                                               \
-      fmaxf(fmaxf(fmaf(nx.c, r.ix, -r.oix), fmaf(ny.c, r.iy, -r.oiy)), fmaxf(fmaf(nz.c, r.iz, -r.oiz), tmin32));       \
-  const float tf##slot =                                                                                               \
-      fminf(fminf(fmaf(fx.c, r.ix, -r.oix), fmaf(fy.c, r.iy, -r.oiy)), fminf(fmaf(fz.c, r.iz, -r.oiz), tmax32));       \
+  const float tn##slot = fmaxf(fmaxf(fmaf((float)nx.c, r.ix, -r.oix), fmaf((float)ny.c, r.iy, -r.oiy)),                \
+                               fmaxf(fmaf((float)nz.c, r.iz, -r.oiz), tmin32));                                        \
+  const float tf##slot = fminf(fminf(fmaf((float)fx.c, r.ix, -r.oix), fmaf((float)fy.c, r.iy, -r.oiy)),                \
+                               fminf(fmaf((float)fz.c, r.iz, -r.oiz), tmax32));                                        \
   const bool h##slot = tn##slot <= tf##slot * slack;                                                                   \
   const uint32_t k##slot = h##slot ? ((__float_as_uint(tn##slot) & ~3u) | slot##u) : 0xffffffffu;
     RTOW_SLAB(x, 0)
@@ -221,7 +243,7 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
     best.prim = -1;
   }
   const V3d o64 = to_f64(o), d64 = to_f64(d);
-  const Bvh4Ray ray = bvh4_ray(o, d);
+  const Bvh4Ray ray = bvh4_ray<FULL>(sc, o, d);
   const Bvh4Stack st = bvh4_stack(sc);
   float tmax32 = round_up_f32(best.t);  // closest hit so far, rounded up
   uint32_t sa = resumed ? w_sa : st.lds;

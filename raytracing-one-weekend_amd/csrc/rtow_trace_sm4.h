@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
 
   // ---- walk state (live for the lanes in PH_WALK; rtow_trace_bvh4.h) ------------------------------
   const Bvh4Stack stk = bvh4_stack(sc);
-  Bvh4Ray ray = bvh4_ray(ro, rd);
+  Bvh4Ray ray = bvh4_ray<FULL>(sc, ro, rd);
   float tmax32 = 0;
   uint32_t sa = stk.lds;
   uint32_t cur = kRefNone, q0 = kRefNone, q1 = kRefNone;
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
     stamps.mark(RG_SHADE);
     // ---- walk start --------------------------------------------------------------------------
     if (phase == PH_START) {
-      ray = bvh4_ray(ro, rd);
+      ray = bvh4_ray<FULL>(sc, ro, rd);
       tmax32 = __builtin_huge_valf();
       sa = stk.lds;
       cur = 0u;  // the root

@@ -84,7 +84,7 @@ class BuildInfo(C.Structure):
         ("bvh_image_bytes", C.c_int32), ("grid_image_bytes", C.c_int32),
         ("bvh_build_ms", C.c_double), ("grid_build_ms", C.c_double), ("upload_ms", C.c_double),
         ("bvh4_nodes", C.c_int32), ("bvh4_image_bytes", C.c_int32),
-        ("ref_tree_nodes", C.c_int32), ("pad_", C.c_int32),
+        ("ref_tree_nodes", C.c_int32), ("bvh4_node_bytes", C.c_int32),
         ("ref_tree_stupid_volume", C.c_double), ("ref_tree_build_ms", C.c_double),
     ]
 

@@ -460,6 +460,49 @@ def test_bvh4_edge_cases(monkeypatch, sm):
         c.close()
 
 
+@pytest.mark.parametrize("sm", [False, True])
+def test_half_node_walk_is_bit_identical_to_the_oracle(monkeypatch, tmp_path, sm):
+    """A mesh whose 4-wide image does not fit LDS whole gets 64-byte nodes with binary16 planes in the mesh's own
+    frame (rtow_bvh4.h): boxes a little bigger, never smaller, so the closest hit — and the strict image — is what
+    the oracle computes with the reference's tree.  suzanne subdivided 2x2 (3,872 triangles), as it is and shrunk and
+    moved off the origin (the frame's centre and scale are then not 0 and 1), trip form and state machine."""
+    import sys
+
+    from conftest import REPO
+    sys.path.insert(0, str(REPO / "scripts"))
+    import make_mesh
+
+    if sm:
+        monkeypatch.setenv("RTOW_BVH4_SM", "1")
+    v, f = make_mesh.load(GOLDEN / "suzanne.obj")
+    tris = make_mesh.subdivide(v, f, 2)
+    c = rtow.Context(0)
+    try:
+        for k, (scale, shift) in enumerate(((1.0, (0.0, 0.0, 0.0)), (0.55, (0.3125, -0.11, 0.27)))):
+            obj = tmp_path / f"m{k}.obj"
+            t = tris * scale + np.array(shift)
+            with open(obj, "w") as fh:
+                for tri in t:
+                    for p in tri:
+                        fh.write(f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}\n")
+                for i in range(len(t)):
+                    fh.write(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n")
+            scene = rtow.HostScene.obj(obj, 16 / 9)
+            assert scene.c.n_triangles == 3872
+            cfg = rtow.make_config(96, 54, 4, 2, 20, seed=5 + k, precision=rtow.F64_STRICT, kernel=rtow.KERNEL_BVH4)
+            img, st = c.render(scene, cfg)
+            bi = c.build_info()
+            assert bi.bvh4_node_bytes == 64 and bi.bvh4_image_bytes > 160 * 1024
+            ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+            assert st.kernel_used == rtow.KERNEL_BVH4 and st.segments == ost.segments
+            assert np.array_equal(img, ref), f"{int((img != ref).sum())} values differ"
+        small = rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9)  # fits LDS whole: binary32 planes
+        c.render(small, rtow.make_config(16, 9, 2, 1, 20, seed=1, precision=rtow.F64_STRICT))
+        assert c.build_info().bvh4_node_bytes == 128
+    finally:
+        c.close()
+
+
 def test_mesh_beyond_the_bvh4_limits_takes_the_binary_walk(ctx, tmp_path):
     """The 4-wide image addresses triangles with 18 bits (rtow_bvh4.h): a mesh of 279,752 triangles (suzanne
     subdivided 17x17) is rendered by the binary threaded walk instead — same surface, so the image agrees with the

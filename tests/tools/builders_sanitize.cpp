@@ -3,6 +3,7 @@
 // without HIP: SAH BVH2 -> threaded image, 4-wide image (triangle meshes), uniform grid with fat lists
 // (static and moving spheres).  Exit code 0 = every image built and validated.
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <random>
@@ -70,6 +71,35 @@ int main(int argc, char **argv) {
     rtow::make_bvh4_image(pairs, tri, pmat, mats, cam, v);
     if (!v.ok || !rtow::validate_bvh4_image(v, nt)) return 60 + rep;
     std::printf("  pair leaves: %d BVH4 nodes, depth %d, %zu bytes\n", v.n_nodes, v.depth, v.blob.size());
+    // the same tree with 64-byte nodes (binary16 planes in the mesh's frame): same links, and every plane at or
+    // outside the binary32 one (give or take that one's own rounding), by no more than 1/3900 of the mesh's extent
+    rtow::Bvh4Image vh;
+    rtow::make_bvh4_image(pairs, tri, pmat, mats, cam, vh, /*half=*/true);
+    if (!vh.ok || !vh.half || !rtow::validate_bvh4_image(vh, nt) || vh.n_nodes != v.n_nodes) return 80 + rep;
+    if (vh.blob.size() != v.blob.size() - (size_t)v.n_nodes * 64) return 82 + rep;
+    double worst = 0.0;
+    for (int i = 0; i < v.n_nodes; ++i) {
+      const float *f = reinterpret_cast<const float *>(v.blob.data() + (size_t)i * 128);
+      const uint16_t *h = reinterpret_cast<const uint16_t *>(vh.blob.data() + (size_t)i * 64);
+      if (std::memcmp(v.blob.data() + (size_t)i * 128 + 96, vh.blob.data() + (size_t)i * 64 + 48, 16) != 0) return 84 + rep;
+      for (int k = 0; k < 3; ++k) {
+        const double extent = 2000.0 / vh.map_s[k];
+        for (int c = 0; c < 4; ++c) {
+          const double lo32 = f[k * 8 + c], hi32 = f[k * 8 + 4 + c];
+          const double lo16 = rtow::half_value(h[k * 8 + c]) / vh.map_s[k] + vh.map_c[k];
+          const double hi16 = rtow::half_value(h[k * 8 + 4 + c]) / vh.map_s[k] + vh.map_c[k];
+          if (std::isinf(lo32)) {  // empty slot: inverted in both
+            if (!(std::isinf(lo16) && lo16 > 0 && std::isinf(hi16) && hi16 < 0)) return 86 + rep;
+            continue;
+          }
+          const double slack32 = 4.0 * 1.2e-7 * std::max({std::fabs(lo32), std::fabs(hi32), 1.0});
+          if (!(lo16 <= lo32 + slack32 && hi16 >= hi32 - slack32)) return 88 + rep;
+          worst = std::max({worst, (lo32 - lo16) / extent, (hi16 - hi32) / extent});
+        }
+      }
+    }
+    if (worst > 1.0 / 3900.0) return 90 + rep;
+    std::printf("  half nodes: %zu bytes, planes moved outwards by at most 1/%.0f of the extent\n", vh.blob.size(), 1.0 / worst);
     tri.insert(tri.end(), tri.begin(), tri.begin() + 12 * 50);  // second round: 50 coincident triangles
   }
   {  // concurrent subtrees (forced on this small mesh), a build whose every thread start fails, and the serial
