@@ -813,6 +813,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       best = closest_hit_bvh4<LDS, STAMPS>(im4, sc, P, ro, rd, rtime, tracing, lane_g, nnode, nprim, stamps, best, w_cur, w_sa,
                                            P.walk_cap, P.walk_max_open);
     } else if constexpr (KERNEL == 3) {
+      if constexpr (STAMPS) stamps.primary = __ballot(tracing && depth == P.max_child_rays);
       best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, tracing, nnode, nprim, stamps, best, t_resume, P.walk_cap,
                                            P.walk_max_open, P.leaf_votes);
     } else if constexpr (KERNEL == 2) {
@@ -912,6 +913,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       atomicAdd(&P.counters[44], stamps.blocks);
       atomicAdd(&P.counters[36], stamps.block_lanes);
       atomicAdd(&P.counters[35], stamps.leaf_lanes);
+      atomicAdd(&P.counters[45], stamps.iters_cam);
+      atomicAdd(&P.counters[46], stamps.phases_cam);
       atomicAdd(&P.counters[13], stamps.iters);
       atomicAdd(&P.counters[14], stamps.trips);
       atomicAdd(&P.counters[15], stamps.phases);

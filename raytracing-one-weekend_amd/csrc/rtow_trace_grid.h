@@ -125,7 +125,9 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   for (;;) {
     if constexpr (ST) {
       stamps.iters += 1;
-      stamps.step_lanes += (unsigned long long)__popcll(__ballot(walking && q1 == 0u));
+      const unsigned long long m_step = __ballot(walking && q1 == 0u);
+      stamps.step_lanes += (unsigned long long)__popcll(m_step);
+      if (m_step != 0ull && (m_step & ~stamps.primary) == 0ull) stamps.iters_cam += 1;
     }
     if (walking && q1 == 0u) {  // (a lane with two cells queued waits for the next leaf phase)
       const uint32_t cw = im.u32(sc.g_off_cells + 4u * (uint32_t)idx);
@@ -168,6 +170,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
       if constexpr (ST) {
         stamps.phases += 1;
         stamps.leaf_lanes += (unsigned long long)__popcll(m_pending);
+        if (m_pending != 0ull && (m_pending & ~stamps.primary) == 0ull) stamps.phases_cam += 1;
       }
       if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
       q0 = q1;

@@ -40,6 +40,9 @@ iters, trips, phases = out[13], out[14], out[15]
 print(f"lanes stepping per step-loop iteration {out[34]/max(iters,1):.1f}; lanes testing per leaf phase {out[35]/max(phases,1):.1f}")
 print(f"wave trips {trips}, step-loop iterations per trip {iters/max(trips,1):.1f}, leaf phases per trip {phases/max(trips,1):.2f}, "
       f"lane-segments per trip {st.segments/max(trips,1):.1f} of 64")
+if out[45] or out[46]:
+    print(f"GRID: step-loop iterations that only camera rays needed {out[45]/max(iters,1)*100:.1f} % of all; leaf phases only camera rays "
+          f"needed {out[46]/max(phases,1)*100:.1f} % (the most a separate treatment of primary rays could take out of the walk)")
 print(f"Philox block evaluations per trip (wave level, new-ray stage): {out[44]/max(trips,1):.2f}; lanes per rejection-loop trip {out[36]/max(out[44]-trips,1):.1f}")
 nw = 4096.0
 print(f"wave end times (ms after first wave start): mean {out[4]/nw/1e5:.3f}  min {out[5]/1e5:.3f}  max {out[6]/1e5:.3f};  queue seen empty (mean over waves) {out[7]/nw/1e5:.3f}")
