@@ -21,5 +21,6 @@ def test_builders_are_clean_under_asan_and_ubsan(tmp_path):
                        env={"ASAN_OPTIONS": "detect_leaks=1"})
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
     assert "thread-start-failure builds give one image" in r.stdout
+    assert "binary16 directed rounding: all 63488 finite values" in r.stdout
     assert "half nodes" in r.stdout and "planes moved outwards by at most" in r.stdout
     assert "968 triangles" in r.stdout and "fat entries of 80 bytes" in r.stdout and "fat entries of 48 bytes" in r.stdout

@@ -130,6 +130,23 @@ int main(int argc, char **argv) {
     rtow::make_bvh4_image(bvh, one, pmat, mats, cam, img4);
     if (!img4.ok || !rtow::validate_bvh4_image(img4, 1)) return 30;
   }
+  {  // binary16 with directed rounding (the half nodes' planes): every finite value maps to itself in both directions,
+     // every point strictly between two neighbours goes down to the lower and up to the upper one
+    auto ordered = [](int32_t k) { return k >= 0 ? (uint16_t)k : (uint16_t)(0x8000u | (uint32_t)(-k - 1)); };
+    for (int32_t k = -0x7c00; k < 0x7bff; ++k) {  // -65504 .. the value below +65504
+      const uint16_t a = ordered(k), b = ordered(k + 1);
+      const double va = rtow::half_value(a), vb = rtow::half_value(b);
+      if (rtow::half_value(rtow::half_directed(va, -1)) != va || rtow::half_value(rtow::half_directed(va, +1)) != va) return 95;
+      if (va == vb) continue;  // -0 and +0
+      const double mid = 0.5 * (va + vb), near_a = va + (vb - va) * 1e-9, near_b = vb - (vb - va) * 1e-9;
+      for (double x : {mid, near_a, near_b})
+        if (rtow::half_value(rtow::half_directed(x, -1)) != va || rtow::half_value(rtow::half_directed(x, +1)) != vb) return 96;
+    }
+    if (rtow::half_directed(1e9, +1) != 0x7c00 || rtow::half_directed(1e9, -1) != 0x7bff || rtow::half_directed(-1e9, -1) != 0xfc00 ||
+        rtow::half_directed(-1e9, +1) != 0xfbff)
+      return 97;
+    std::printf("binary16 directed rounding: all %d finite values and the gaps between them\n", 2 * 0x7c00);
+  }
   // ---- sphere scenes: grid with fat lists, static and moving
   for (int moving = 0; moving < 2; ++moving) {
     std::mt19937 rng(7);
