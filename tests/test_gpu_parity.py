@@ -801,6 +801,16 @@ def test_fast_build_image_does_not_depend_on_nstreams(ctx):
         assert all(a + c == b for (a, c), (b, _) in zip(sched, sched[1:]))  # contiguous sample ranges
         assert all(c == 12 for _, c in sched)  # the divisor of 48 nearest 10
     assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
+    # a scene of triangles only aims at 16 samples per item (longer, resumable walks), again whatever nstreams is
+    mesh = rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9)
+    mimgs = []
+    for ns in (1, 4):
+        mcfg = rtow.make_config(96, 54, 64, ns, 20, seed=5, precision=rtow.F64_FAST)
+        mimgs.append(ctx.render(mesh, mcfg)[0])
+        pairs = (C.c_uint32 * 128)()
+        n = rtow.lib().rtow_debug_schedule(ctx._h, C.byref(mcfg), pairs, 64)
+        assert n == 4 and all(pairs[2 * i + 1] == 16 for i in range(n))
+    assert np.array_equal(mimgs[0], mimgs[1])
     strict, _ = ctx.render(scene, rtow.make_config(240, 160, 48, 4, 50, seed=5, precision=rtow.F64_STRICT))
     assert np.abs(imgs[0] - strict).mean() / 48 <= 1e-4
     # a stream range is scheduled over its own samples: two accumulated halves stay within the same tolerance
