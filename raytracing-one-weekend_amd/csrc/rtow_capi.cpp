@@ -1166,6 +1166,9 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
     if ((rc = c->spill.ensure(std::max<size_t>((size_t)extra * (size_t)n_lanes * sizeof(uint32_t), 16)))) return rc;
   }
 
+#ifdef RTOW_TAILSTAT
+  if ((rc = c->spill.ensure(std::max<size_t>((size_t)n_lanes, 16)))) return rc;  // 8 words of 8 bytes per wave
+#endif
   rtow::TraceParams P;
   std::memset(&P, 0, sizeof P);
   P.sc = scene;
@@ -1256,6 +1259,17 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   int lrc = strict ? rtow::launch_trace_strict(P, launch_kernel, (int)grid, block, lds_bytes, st)
             : f32  ? rtow::launch_trace_f32(P, launch_kernel, (int)grid, block, lds_bytes, st)
                    : rtow::launch_trace_fast(P, launch_kernel, (int)grid, block, lds_bytes, st);
+#ifdef RTOW_TAILSTAT
+  if (const char *path = std::getenv("RTOW_TAILSTAT_OUT")) {
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> ts((size_t)n_lanes / 64 * 8);
+    HIPCHK(hipMemcpy(ts.data(), c->spill.p, ts.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE *f = std::fopen(path, "wb")) {
+      std::fwrite(ts.data(), 8, ts.size(), f);
+      std::fclose(f);
+    }
+  }
+#endif
   if (lrc != 0) return fail(RTOW_EHIP, "trace kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
   if (slot >= 0) {
     HIPCHK(hipEventRecord(c->ev[slot][1], st));

@@ -367,6 +367,10 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
   uint32_t tail_trips = 0u;
   ItemPool pool;  // wave-uniform: this wave's batch of work items
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+#ifdef RTOW_TAILSTAT  // (experiment build: what a wave still holds when it first finds the queue empty, and how long that takes)
+  unsigned long long ts_start = __builtin_amdgcn_s_memrealtime(), ts_empty = 0ull;
+  uint32_t ts_trips = 0u, ts_trips_after = 0u, ts_live = 0u, ts_left = 0u, ts_pool = 0u;
+#endif
   Stamps<STAMPS> stamps;
   stamps.start();
   unsigned long long t_empty = 0ull;  // diagnostic: when this wave first saw the queue empty
@@ -412,6 +416,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       if (need_item) {
         if (mine >= (unsigned long long)kp->n_items) {
           done = true;
+#ifdef RTOW_TAILSTAT
+          if (ts_empty == 0ull) ts_empty = 1ull;  // marked; the wave-level snapshot is taken below
+#endif
           if constexpr (STAMPS) {
             if (t_empty == 0ull) t_empty = __builtin_amdgcn_s_memrealtime();
           }
@@ -427,6 +434,24 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         }
       }
     }
+#ifdef RTOW_TAILSTAT
+    {
+      const bool first = __ballot(ts_empty == 1ull) != 0ull && __ballot(ts_empty > 1ull) == 0ull;
+      if (first) {  // wave-uniform: the first trip in which some lane found the queue empty
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        ts_live = (uint32_t)__popcll(__ballot(!done));
+        uint32_t sl = (!done && s_left > 0) ? (uint32_t)s_left : 0u;
+        for (int off = 32; off >= 1; off >>= 1) sl += __shfl_xor(sl, off);
+        ts_left = sl;
+        ts_pool = pool.end - pool.next;
+        ts_empty = now < 2ull ? 2ull : now;
+      } else if (__ballot(ts_empty > 1ull) != 0ull) {
+        ts_empty = (unsigned long long)__shfl((long long)ts_empty, __ffsll((long long)__ballot(ts_empty > 1ull)) - 1);
+      }
+      ++ts_trips;
+      if (__ballot(ts_empty > 1ull) != 0ull) ++ts_trips_after;
+    }
+#endif
     // ---- tail: sample donation ------------------------------------------------------------
     // Once the queue is empty a wave is as slow as its slowest lane's item (up to spt samples of
     // up to max_child_rays segments each) while its other lanes idle.  An idle lane therefore
@@ -921,6 +946,19 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     }
   }
 
+#ifdef RTOW_TAILSTAT
+  if (lane == 0 && P.spill != nullptr) {  // (the experiment borrows the BVH4 spill pointer for its table: 8 words per wave)
+    unsigned long long *ts = (unsigned long long *)P.spill + (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 8;
+    ts[0] = ts_start;
+    ts[1] = ts_empty;
+    ts[2] = __builtin_amdgcn_s_memrealtime();
+    ts[3] = ts_trips;
+    ts[4] = ts_trips_after;
+    ts[5] = ts_live;
+    ts[6] = ts_left;
+    ts[7] = ts_pool;
+  }
+#endif
   // stats: one atomic per wave and counter
   unsigned long long t0 = nseg, t1 = nprim, t2 = nnode;
 #pragma unroll
