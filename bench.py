@@ -572,7 +572,7 @@ def main():
             L = rtow.lib()
             L.rtow_render_rgb8.argtypes = [C2.c_void_p, C2.POINTER(rtow.Scene), C2.POINTER(rtow.Config), C2.c_void_p,
                                            C2.POINTER(rtow.Stats)]
-            n_e2e = 3
+            n_e2e = 10  # (≈ 90 ms per entry point: three calls scattered by ±1 % from run to run)
 
             def timed(fn):
                 fn()
