@@ -1166,7 +1166,8 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
     if ((rc = c->spill.ensure(std::max<size_t>((size_t)extra * (size_t)n_lanes * sizeof(uint32_t), 16)))) return rc;
   }
 
-#ifdef RTOW_TAILSTAT
+#ifdef RTOW_TAILSTAT  // (experiment build, scripts/tailstat.py; sphere scenes only: the BVH4 kernel needs its spill array itself)
+  if (kernel == RTOW_KERNEL_BVH4) return fail(RTOW_EINVAL, "RTOW_TAILSTAT builds do not run the BVH4 kernel");
   if ((rc = c->spill.ensure(std::max<size_t>((size_t)n_lanes, 16)))) return rc;  // 8 words of 8 bytes per wave
 #endif
   rtow::TraceParams P;
