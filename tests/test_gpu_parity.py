@@ -503,6 +503,45 @@ def test_half_node_walk_is_bit_identical_to_the_oracle(monkeypatch, tmp_path, sm
         c.close()
 
 
+def test_meshes_around_the_lds_limit_switch_node_format_and_stay_bit_identical(tmp_path):
+    """The node format of the 4-wide image is decided by its size (rtow_capi.cpp): meshes of 850 … 1,400 triangles —
+    the first N of suzanne subdivided 2x2 — straddle the point where the binary32 image plus eight stack entries per
+    lane stops fitting the 160 KB of LDS.  Each renders bit for bit like the oracle, whichever side it falls on, and
+    both formats occur."""
+    import sys
+
+    from conftest import REPO
+    sys.path.insert(0, str(REPO / "scripts"))
+    import make_mesh
+
+    v, f = make_mesh.load(GOLDEN / "suzanne.obj")
+    tris = make_mesh.subdivide(v, f, 2)
+    formats = set()
+    c = rtow.Context(0)
+    try:
+        for n in (850, 1000, 1100, 1400):
+            obj = tmp_path / f"first{n}.obj"
+            with open(obj, "w") as fh:
+                for tri in tris[:n]:
+                    for p in tri:
+                        fh.write(f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}\n")
+                for i in range(n):
+                    fh.write(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n")
+            scene = rtow.HostScene.obj(obj, 16 / 9)
+            cfg = rtow.make_config(64, 36, 4, 2, 20, seed=n, precision=rtow.F64_STRICT, kernel=rtow.KERNEL_BVH4)
+            img, st = c.render(scene, cfg)
+            bi = c.build_info()
+            formats.add(bi.bvh4_node_bytes)
+            wide = bi.bvh4_image_bytes + (64 * bi.bvh4_nodes if bi.bvh4_node_bytes == 64 else 0)  # with 128-byte nodes
+            assert (bi.bvh4_node_bytes == 128) == (wide + 8 * 4096 <= 160 * 1024), (n, bi.bvh4_image_bytes, bi.bvh4_nodes)
+            ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8)
+            assert st.kernel_used == rtow.KERNEL_BVH4 and st.segments == ost.segments, n
+            assert np.array_equal(img, ref), (n, int((img != ref).sum()))
+    finally:
+        c.close()
+    assert formats == {64, 128}
+
+
 def test_mesh_beyond_the_bvh4_limits_takes_the_binary_walk(ctx, tmp_path):
     """The 4-wide image addresses triangles with 18 bits (rtow_bvh4.h): a mesh of 279,752 triangles (suzanne
     subdivided 17x17) is rendered by the binary threaded walk instead — same surface, so the image agrees with the
