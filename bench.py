@@ -98,6 +98,8 @@ def parse():
     ap.add_argument("--workload", choices=list(WORKLOADS), default="cover")
     ap.add_argument("--no-scaling-base", action="store_true",
                     help="N=1: skip the extra configs[2] (500 spp) measurement on this GPU")
+    ap.add_argument("--no-scale-projection", action="store_true",
+                    help="N=1: skip timing every rank's share of configs[2] at N = 2/4/8 on this GPU")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N=1: skip the shortened runs of the other BASELINE configs")
     ap.add_argument("--no-end-to-end", action="store_true")
@@ -399,6 +401,50 @@ def other_config(name, a, dev, precision, steps, stress=False):
     return line
 
 
+def strip_height(H, world):
+    """Rows per strip for `world` ranks: 8 (8x8-pixel tiles) when the strips deal out evenly, else 4 (16x4 tiles)."""
+    if os.environ.get("RTOW_BENCH_TILE_ROWS"):  # experiment knob: strip height (also the tile shape: 64 / rows wide)
+        return int(os.environ["RTOW_BENCH_TILE_ROWS"])
+    return 8 if H % (8 * world) == 0 else (4 if H % (4 * world) == 0 else 8)
+
+
+def scale_projection(ctx, W, H, depth, precision, kernel, dev, stream, base_value, launches=3, ranks_of=(2, 4, 8)):
+    """configs[2] (cover, 500 spp) as every rank of an N-GPU run would trace it, timed ONE RANK AT A TIME on
+    this GPU: for N in 2/4/8 and bench.py's own strip height, rank r's strips (rtow_config_t rank/nranks/
+    tile_rows — the launch that rank runs, same scene, same seed) with HIP events around the trace kernel and
+    the host clock around trace + reduce.  What it cannot hold: the gather (W*H*24 B / N per rank over xGMI,
+    ~0.1 ms) and rank start-up skew.  Projection = W*H*500 / max_r(step ms of rank r)."""
+    out = {"workload": f"configs[2]: {W}x{H}, 500 spp, {depth} bounces; each rank's strips traced alone on this GPU",
+           "launches_per_rank": launches, "base_Msamples_per_s_1gpu": base_value, "by_n": []}
+    spp = 500
+    for N in ranks_of:
+        tr = strip_height(H, N)
+        per_rank = []
+        for r in range(N):
+            cfg = rtow.make_config(W, H, spp, spp // SAMPLES_PER_ITEM, depth, seed=SEED, precision=precision,
+                                   kernel=kernel, rank=r, nranks=N, tile_rows=tr)
+            rows = rtow.local_rows(cfg)
+            buf = torch.zeros((len(rows), W, 3), dtype=torch.float64, device=dev)
+            ms, kms, st = timed_render_loop(ctx, cfg, buf.data_ptr(), stream.cuda_stream, dev, launches, 1)
+            per_rank.append({"rank": r, "rows": len(rows), "step_ms": round(ms, 4), "kernel_ms": round(kms, 4),
+                             "segments_per_sample": round(st.segments / max(st.samples, 1), 4)})
+            del buf
+        step = [p["step_ms"] for p in per_rank]
+        kern = [p["kernel_ms"] for p in per_rank]
+        proj = W * H * spp / (max(step) * 1e-3) / 1e6
+        out["by_n"].append({
+            "n_gpus": N, "tile_rows": tr, "per_rank": per_rank,
+            "step_ms_max": round(max(step), 4), "step_ms_mean": round(sum(step) / N, 4),
+            "kernel_ms_max": round(max(kern), 4), "kernel_ms_mean": round(sum(kern) / N, 4),
+            "imbalance_max_over_mean": round(max(kern) / (sum(kern) / N), 4),
+            "projected_Msamples_per_s": round(proj, 1),
+            "projected_efficiency": round(proj / (N * base_value), 4) if base_value else None,
+        })
+    out["note"] = ("efficiency = projected / (N x the same frame on this one GPU, scaling_base); excludes the one "
+                   "gather per frame and start-up skew, which the driver's SCALE run adds")
+    return out
+
+
 def samples_per_item(ctx, cfg):
     """Length of a work item of this render (rtow_debug_schedule): spp / nstreams in the strict build, the
     divisor of the sample range nearest the aimed-at length in the fast builds (10; 16 for a mesh)."""
@@ -449,9 +495,7 @@ def main():
     spp = a.spp or (spp0 if (world == 1 or kind not in ("cover", "moving")) else 500)
     nstreams = max(1, spp // spi)
     # strips of 8 rows (8x8-pixel tiles: +0.8 % over 16x4) when they deal out evenly, else 4
-    tile_rows = 8 if H % (8 * world) == 0 else (4 if H % (4 * world) == 0 else 8)
-    if os.environ.get("RTOW_BENCH_TILE_ROWS"):  # experiment knob: strip height (also the tile shape: 64 / rows wide)
-        tile_rows = int(os.environ["RTOW_BENCH_TILE_ROWS"])
+    tile_rows = strip_height(H, world)
     precision = {"fast": rtow.F64_FAST, "strict": rtow.F64_STRICT, "f32": rtow.F32}[a.precision]
     kernel = {"auto": rtow.KERNEL_AUTO, "brute": rtow.KERNEL_BRUTE, "bvh": rtow.KERNEL_BVH, "grid": rtow.KERNEL_GRID,
               "bvh4": rtow.KERNEL_BVH4, "reftree": rtow.KERNEL_REFTREE}[a.kernel]
@@ -601,6 +645,31 @@ def main():
             out["ms_per_step_e2e"] = out["end_to_end"]["rgb8"]["ms_per_call"]
             out["e2e_over_device_resident"] = round(out["value_e2e"] / value, 4)
             ctx.upload(scene)  # (rtow_render uploads only what its kernel reads: the full scene again for what follows)
+            # The multi-GPU product path (csrc/rtow_multi.cpp) with a ONE-device handle, RCCL on: what a frame costs
+            # beyond the kernel — worker hand-off, one ncclGather, the row-placement kernel, one D2H into caller memory.
+            # (rtow_render_rgb8 above also uploads the scene per call; the handle renders a resident scene.)
+            try:
+                mh = rtow.MultiContext([dev.index], use_rccl=True)
+                mh.upload(scene)
+                cfg_m = rtow.make_config(W, H, spp, nstreams, DEPTH, seed=SEED, precision=precision, kernel=kernel,
+                                         tile_rows=tile_rows)
+                m8 = timed(lambda: rtow.check(L.rtow_multi_render_rgb8(mh._h, C2.byref(cfg_m), host8.ctypes.data_as(C2.c_void_p),
+                                                                      None), "rtow_multi_render_rgb8"))
+                m64 = timed(lambda: rtow.check(L.rtow_multi_render(mh._h, C2.byref(cfg_m), host.ctypes.data_as(C2.POINTER(C2.c_double)),
+                                                                   None), "rtow_multi_render"))
+                mh.close()
+                out["multi_handle"] = {
+                    "devices": [dev.index], "use_rccl": True, "calls": n_e2e,
+                    "rgb8": {"value": round(W * H * spp_eff / m8 / 1e6, 3), "ms_per_frame": round(m8 * 1e3, 4),
+                             "over_rtow_render_rgb8": round(e8 / m8, 4)},
+                    "f64": {"value": round(W * H * spp_eff / m64 / 1e6, 3), "ms_per_frame": round(m64 * 1e3, 4),
+                            "over_rtow_render": round(e1 / m64, 4)},
+                    "region": "rtow_multi_render{_rgb8,}(): resident scene; per frame one trace launch, ONE ncclGather "
+                              "(one-rank communicator), rows placed by a kernel on the first device, ONE D2H straight "
+                              "into caller memory (src/render.cpp:176-186)",
+                }
+            except rtow.RtowError as e:  # (no librccl.so on this machine: the line says so instead of failing the bench)
+                out["multi_handle"] = {"error": str(e)}
         if world == 1 and a.workload == "cover" and not a.no_reference_boundary:
             # What a drop-in caller of render(scene, cfg) gets: Config::nthreads = 4 (src/render.h:18) -> nstreams = 4,
             # at the two sample counts of BASELINE configs[1] / [2], device-resident and through the boundary call
@@ -648,6 +717,9 @@ def main():
                 "value": round(W * H * 500 / e5 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(e5 * 1e3, 4),
                 "steps": 3,
             }
+            if not a.no_scale_projection:
+                out["scale_projection"] = scale_projection(ctx, W, H, DEPTH, precision, kernel, dev, stream,
+                                                           out["scaling_base"]["value"])
         if world == 1 and a.workload == "cover" and not a.spp and not a.no_other_configs:
             out["other_configs"] = [other_config(n, a, dev, precision, s)
                                     for n, s in (("moving", 4), ("suzanne", 3), ("mesh100k", 2))]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTOW_ABI_VERSION 5
+#define RTOW_ABI_VERSION 6
 
 /* error codes */
 #define RTOW_OK 0
@@ -186,7 +186,12 @@ int rtow_ctx_create(int device_id, rtow_ctx **out);
 void rtow_ctx_destroy(rtow_ctx *ctx);
 
 /* Copy the scene into HBM (and build the device BVH).  The scene stays
- * resident until the next upload or ctx destroy. */
+ * resident until the next upload or ctx destroy.
+ * Ordering: the copies and build kernels are QUEUED on the null stream and the call returns without waiting for
+ * them.  A render on the null stream or on a blocking stream is ordered behind them by the runtime; a render on a
+ * hipStreamNonBlocking stream (every torch.cuda.Stream() side stream) is ordered behind them by the library (it
+ * makes the stream wait for an event recorded behind the upload).  build_info.upload_ms is therefore the host time
+ * of the call, not the completion time of the copies. */
 int rtow_scene_upload(rtow_ctx *ctx, const rtow_scene_t *scene);
 
 /* Who builds the BVH image at rtow_scene_upload (replaces the reference's BVHNode constructor,
@@ -237,9 +242,20 @@ int rtow_local_row_list(const rtow_config_t *cfg, int32_t *rows_out, int32_t cap
  * write_color divides by spp.  `hip_stream` is a hipStream_t (NULL = default
  * stream); the call enqueues work on it and returns without synchronising,
  * unless `stats` is non-NULL, in which case it synchronises the stream and
- * fills `stats`. */
+ * fills `stats`.
+ * Samples are never dropped silently: the trace kernel's end-of-launch protocol has a structural trip bound (never
+ * observed to fire); lanes that reach it count themselves in a device word, and every entry point that waits for the
+ * device — this one with `stats`, rtow_render, rtow_render_rgb8, rtow_multi_render* — returns RTOW_EHIP instead of
+ * RTOW_OK when the word is non-zero.  The asynchronous form (stats == NULL) reports it at rtow_profile_collect. */
 int rtow_render_device(rtow_ctx *ctx, const rtow_config_t *cfg, void *d_rgb_sums,
                        void *hip_stream, rtow_stats_t *stats);
+
+/* The same with write_color run on the device (src/render.cpp:11-20): `d_rgb8` is a DEVICE pointer to
+ * local_rows*image_width*3 BYTES, the values the reference prints for this rank's rows.  The f64 sums stay in the
+ * context's workspace (write_color is fused into the reduce kernel when the render is one launch).  cfg->accumulate
+ * must be 0.  Asynchronous on `hip_stream` like rtow_render_device.  (What every rank of rtow_multi_render_rgb8 runs.) */
+int rtow_render_device_rgb8(rtow_ctx *ctx, const rtow_config_t *cfg, void *d_rgb8, void *hip_stream,
+                            rtow_stats_t *stats);
 
 /* write_color on the device (reference src/render.cpp:11-20): for each of the n_values
  * doubles of `d_rgb_sums`, byte = int(256 * clamp(sqrt(sum / spp_effective), 0, 0.999)) into
@@ -264,8 +280,10 @@ int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out48);
  * sample count), one work item per pixel and level.  RTOW_F64_STRICT: one level per stream (spp / nstreams
  * samples, the reference's threads, src/render.cpp:151-166), summed in stream order like the reference.  Fast
  * builds: the same samples in levels of ONE length that does not depend on nstreams — the divisor of the sample
- * range nearest RTOW_SCHED_CHUNK (10; 16 when the resident scene is a triangle mesh) — so that Config::nthreads
- * keeps its arithmetic meaning without setting the size of a work item (csrc/rtow_capi.cpp, level_plan).  Returns the number of levels (writes at most
+ * range nearest RTOW_SCHED_CHUNK (10; RTOW_SCHED_CHUNK_MESH = 16 when the resident scene is a triangle mesh) — so
+ * that Config::nthreads keeps its arithmetic meaning without setting the size of a work item (csrc/rtow_capi.cpp,
+ * level_plan).  A sample range with no divisor within a factor of two of that length (101, 127: primes) is cut into
+ * levels of exactly that length with the remainder added to the LAST level (101 = 9 x 10 + 11).  Returns the number of levels (writes at most
  * `capacity_pairs` of them).  `ctx` may be NULL: the table of a new context (pure host arithmetic, usable
  * without a GPU). */
 int rtow_debug_schedule(rtow_ctx *ctx, const rtow_config_t *cfg, uint32_t *out_pairs, int32_t capacity_pairs);
@@ -275,7 +293,11 @@ int rtow_debug_schedule(rtow_ctx *ctx, const rtow_config_t *cfg, uint32_t *out_p
  * and device-built images byte for byte with it. */
 int rtow_debug_image(rtow_ctx *ctx, int32_t which, void *out, int64_t capacity, int64_t *size_out);
 
-/* Convenience: upload + render + copy this rank's rows to host memory. */
+/* Convenience: upload + render + copy this rank's rows to host memory.
+ * Lean upload: rtow_render / rtow_render_rgb8 know their config and build only the structures ITS kernel reads
+ * (the cover scene through the grid kernel needs no BVH, no 4-wide image, no binary32 images).  The scene they
+ * leave resident is therefore partial: a later rtow_render_device with another kernel or precision is refused with
+ * RTOW_ENOSCENE until rtow_scene_upload (which builds everything) has run. */
 int rtow_render(rtow_ctx *ctx, const rtow_scene_t *scene, const rtow_config_t *cfg,
                 double *rgb_sums_host, rtow_stats_t *stats);
 
@@ -299,8 +321,14 @@ int rtow_render_multi(int32_t n_devices, const int32_t *device_ids, const rtow_s
  * streams, buffers, worker threads and — by far the largest item — the RCCL communicator on every call
  * (it is create + upload + render + destroy).  The handle owns all of them; rtow_multi_upload builds
  * the scene's acceleration structures once per device (concurrently); rtow_multi_render is then one
- * trace launch per device, the one ncclGather enqueued behind them on the same streams, one
- * device-to-host copy into pinned memory and the placement of the rows.  One call in flight per handle.
+ * trace launch per device, the one ncclGather enqueued behind them on the same streams, a small kernel on the
+ * first device that puts the strips' rows in place, and ONE device-to-host copy straight into the caller's buffer
+ * (no host pass over the pixels).  One call in flight per handle.
+ * rtow_multi_render_rgb8: the same with write_color run by the rank that owns the pixel (the fused reduce of
+ * rtow_render_device_rgb8), so the gather and the copy move 3 bytes per pixel instead of 24; `rgb8_host` receives
+ * image_height*image_width*3 bytes, equal to a one-device rtow_render_rgb8 of the same config.
+ * If a rank cannot enqueue its side of the gather, every communicator is aborted (ncclCommAbort) before anything
+ * is waited for, the call returns RTOW_EHIP and the handle refuses further frames: an error is a code, never a hang.
  * rtow_multi_build_info reports the first device's build (every device builds the same structures). */
 typedef struct rtow_multi rtow_multi;
 int rtow_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_rccl, rtow_multi **out);
@@ -308,6 +336,7 @@ int rtow_multi_set_builder(rtow_multi *m, int32_t builder);
 int rtow_multi_upload(rtow_multi *m, const rtow_scene_t *scene);
 int rtow_multi_build_info(rtow_multi *m, rtow_build_info_t *out);
 int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats);
+int rtow_multi_render_rgb8(rtow_multi *m, const rtow_config_t *cfg, unsigned char *rgb8_host, rtow_stats_t *stats);
 void rtow_multi_destroy(rtow_multi *m);
 
 /* ---- host-side scene construction (no GPU needed) --------------------------

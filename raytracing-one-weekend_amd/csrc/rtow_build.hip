@@ -12,7 +12,7 @@
 // All kernels are index-checked against `n`; the emitted links are validated on the device
 // before the trace kernel may use the image (same rules as validate_scene_image()).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <math.h>
 #include <stdint.h>
 
@@ -350,8 +350,7 @@ int lbvh_build(const double *sph, const double *sph_r, const double *mov, const 
               dev_alloc(s->ibox, ci * 6) && dev_alloc(s->size, ci) && dev_alloc(s->flags, ci) &&
               dev_alloc(s->glob, 8);
     if (ok) {
-      ok = hipcub::DeviceRadixSort::SortPairs(nullptr, s->sort_tmp_bytes, s->keys_a, s->keys_b, s->vals_a,
-                                              s->vals_b, cap, 0, 63, st) == hipSuccess &&
+      ok = rocprim::radix_sort_pairs(nullptr, s->sort_tmp_bytes, s->keys_a, s->keys_b, s->vals_a, s->vals_b, (size_t)cap, 0u, 63u, st) == hipSuccess &&
            hipMalloc(&s->sort_tmp, s->sort_tmp_bytes ? s->sort_tmp_bytes : 16) == hipSuccess;
     }
     if (!ok) {
@@ -374,8 +373,7 @@ int lbvh_build(const double *sph, const double *sph_r, const double *mov, const 
     hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, st, s->pbox64, n, cam_scale, s->glob, s->pbox, s->keys_a,
                        s->vals_a);
     size_t tmp_bytes = s->sort_tmp_bytes;
-    good = hipcub::DeviceRadixSort::SortPairs(s->sort_tmp, tmp_bytes, s->keys_a, s->keys_b, s->vals_a,
-                                              s->vals_b, n, 0, 63, st) == hipSuccess;
+    good = rocprim::radix_sort_pairs(s->sort_tmp, tmp_bytes, s->keys_a, s->keys_b, s->vals_a, s->vals_b, (size_t)n, 0u, 63u, st) == hipSuccess;
   }
   int32_t root_size = 1;
   if (good && n > 1) {

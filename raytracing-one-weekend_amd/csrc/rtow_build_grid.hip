@@ -15,7 +15,8 @@
 //   phase 3  fill (atomic cursors), sort each cell's list, cell words + id section + large list
 //            into the image
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <math.h>
 #include <stdint.h>
 
@@ -245,8 +246,8 @@ int grid_build_phase1(const double *sph, const double *sph_r, const double *mov,
               galloc(s->is_large, cap) && galloc(s->large_rank, cap) && galloc(s->glob, 16);
     size_t a = 0, b = 0;
     if (ok) {
-      ok = hipcub::DeviceRadixSort::SortKeys(nullptr, a, s->diag, s->diag_sorted, (int)cap, 0, 64, st) == hipSuccess &&
-           hipcub::DeviceScan::ExclusiveSum(nullptr, b, s->is_large, s->large_rank, (int)cap, st) == hipSuccess;
+      ok = rocprim::radix_sort_keys(nullptr, a, s->diag, s->diag_sorted, cap, 0u, 64u, st) == hipSuccess &&
+           rocprim::exclusive_scan(nullptr, b, s->is_large, s->large_rank, 0u, cap, rocprim::plus<uint32_t>(), st) == hipSuccess;
       s->tmp_bytes = a > b ? a : b;
       ok = ok && hipMalloc(&s->tmp, s->tmp_bytes ? s->tmp_bytes : 16) == hipSuccess;
     }
@@ -265,13 +266,13 @@ int grid_build_phase1(const double *sph, const double *sph_r, const double *mov,
     hipLaunchKernelGGL(kg_bounds, dim3(G), dim3(B), 0, st, sph, sph_r, mov, tri, ns, nm, nt, time0, time1, s->pb,
                        s->diag);
     size_t tb = s->tmp_bytes;
-    good = hipcub::DeviceRadixSort::SortKeys(s->tmp, tb, s->diag, s->diag_sorted, n, 0, 64, st) == hipSuccess;
+    good = rocprim::radix_sort_keys(s->tmp, tb, s->diag, s->diag_sorted, (size_t)n, 0u, 64u, st) == hipSuccess;
   }
   if (good) {
     hipLaunchKernelGGL(kg_classify, dim3(G), dim3(B), 0, st, s->pb, s->diag, s->diag_sorted, n, large_ratio,
                        s->is_large, s->glob);
     size_t tb = s->tmp_bytes;
-    good = hipcub::DeviceScan::ExclusiveSum(s->tmp, tb, s->is_large, s->large_rank, n, st) == hipSuccess;
+    good = rocprim::exclusive_scan(s->tmp, tb, s->is_large, s->large_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st) == hipSuccess;
   }
   unsigned long long h[8];
   good = good && hipMemcpyAsync(h, s->glob, sizeof h, hipMemcpyDeviceToHost, st) == hipSuccess &&
@@ -307,7 +308,7 @@ int grid_build_phase2(void *handle, const float gminf[3], const float cellf[3], 
           galloc(s->cursor, (size_t)s->cell_capacity)))
       return 2;
     size_t b = 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, b, s->count, s->first, (int)s->cell_capacity, st) != hipSuccess) return 2;
+    if (rocprim::exclusive_scan(nullptr, b, s->count, s->first, 0u, (size_t)s->cell_capacity, rocprim::plus<uint32_t>(), st) != hipSuccess) return 2;
     if (b > s->tmp_bytes) {
       (void)hipFree(s->tmp);
       s->tmp = nullptr;
@@ -329,7 +330,7 @@ int grid_build_phase2(void *handle, const float gminf[3], const float cellf[3], 
     hipLaunchKernelGGL(kg_register<false>, dim3((s->n + B - 1) / B), dim3(B), 0, st, s->pb, s->is_large, s->n, g,
                        s->count, s->first, s->cursor, (uint32_t *)nullptr);
     size_t tb = s->tmp_bytes;
-    good = hipcub::DeviceScan::ExclusiveSum(s->tmp, tb, s->count, s->first, (int)ncell, st) == hipSuccess;
+    good = rocprim::exclusive_scan(s->tmp, tb, s->count, s->first, 0u, (size_t)ncell, rocprim::plus<uint32_t>(), st) == hipSuccess;
   }
   if (good)
     hipLaunchKernelGGL(kg_check, dim3(((int)ncell + B - 1) / B), dim3(B), 0, st, s->count, s->first, (int)ncell,

@@ -259,6 +259,8 @@ struct Knobs {
                                   //   pixel, like the strict build).  5 / 10 / 20 / 25: 10.88 / 11.18 / 10.22 / 9.55 Gsamples/s on C2
   int sched_chunk_mesh = 16;      //   ... for a scene of triangles only (its walks are longer and resumable: fewer, longer items;
                                   //   4 / 8 / 16 / 32 samples: 4.60 / 4.64 / 4.69 / 4.68 Gsamples/s on C4, 2.29 / 2.30 / 2.32 / 2.32 on C5)
+  int tail_bound = 0;             // RTOW_TAIL_BOUND (tests only): trips of the end-of-launch protocol before a wave gives up
+                                  //   its samples (0 = the structural bound); a small value forces the RTOW_EHIP path
   void read() {
     auto geti = [](const char *n, int d) { const char *e = std::getenv(n); return e ? std::atoi(e) : d; };
     auto getd = [](const char *n, double d) { const char *e = std::getenv(n); return e ? std::atof(e) : d; };
@@ -300,7 +302,8 @@ struct Knobs {
     }
     bvh4_stack_k = std::min(std::max(geti("RTOW_BVH4_STACK_K", 0), 0), 64);
     sched_chunk = std::min(std::max(geti("RTOW_SCHED_CHUNK", 10), 0), 4096);
-    sched_chunk_mesh = std::min(std::max(geti("RTOW_SCHED_CHUNK", 16), 0), 4096);
+    sched_chunk_mesh = std::min(std::max(geti("RTOW_SCHED_CHUNK_MESH", 16), 0), 4096);
+    tail_bound = std::max(geti("RTOW_TAIL_BOUND", 0), 0);
   }
 };
 
@@ -349,6 +352,11 @@ struct rtow_ctx {
   double fuse_spp = 0.0;
   bool fuse_used = false;
   DevBuf counters_init;  // what the 48 counters look like before a launch (one D2D copy instead of three memsets)
+  // Samples given up at the end-of-launch bound (rtow_trace_body.h): a device word no launch resets, mirrored into
+  // pinned memory behind every render; every entry point that waits for the device checks it (check_dropped)
+  DevBuf dropped;
+  unsigned long long *h_dropped = nullptr;
+  hipEvent_t upload_ev = nullptr;  // recorded on the null stream behind the last copy / build kernel of a scene upload
   // launch shape per [precision][kernel-1]: blocks per CU (0 = not queried yet)
   int occ[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   // profiling ring: event pairs around each trace-kernel launch since the last collect
@@ -392,6 +400,13 @@ static int impl_ctx_create(int device_id, rtow_ctx **out) {
   for (int k = 0; k < 2 && he == hipSuccess; ++k) he = hipEventCreate(&c->call_ev[k]);
   if (he == hipSuccess)
     he = hipHostMalloc((void **)&c->h_counters, 48 * sizeof(unsigned long long), hipHostMallocDefault);
+  if (he == hipSuccess) he = hipHostMalloc((void **)&c->h_dropped, sizeof(unsigned long long), hipHostMallocDefault);
+  if (he == hipSuccess) {
+    *c->h_dropped = 0ull;
+    he = hipEventCreateWithFlags(&c->upload_ev, hipEventDisableTiming);
+  }
+  if (he == hipSuccess && c->dropped.ensure(sizeof(unsigned long long)) != RTOW_OK) he = hipErrorOutOfMemory;
+  if (he == hipSuccess) he = hipMemset(c->dropped.p, 0, sizeof(unsigned long long));
   if (he != hipSuccess) {
     rtow_ctx_destroy(c);
     return fail(RTOW_EHIP, "rtow_ctx_create: %s", hipGetErrorString(he));
@@ -406,8 +421,11 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   (void)hipDeviceSynchronize();
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
-                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->rtree, &c->counters_init})
+                    &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->rtree, &c->counters_init,
+                    &c->dropped})
     b->release();
+  if (c->h_dropped) (void)hipHostFree(c->h_dropped);
+  if (c->upload_ev) (void)hipEventDestroy(c->upload_ev);
   if (c->arena.p) (void)hipHostFree(c->arena.p);
   for (int i = 0; i < kEventRing; ++i)
     for (int k = 0; k < 2; ++k)
@@ -823,6 +841,10 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
     for (int i = 0; i < 21; ++i) cam32[i] = (float)cd[i];
     if ((rc = upload(c->cam32_dev, cam32))) return rc;
   }
+  // Ordering contract (include/rtow.h): the copies and build kernels above are queued on the null stream without a
+  // host wait; a render on ANOTHER stream (a hipStreamNonBlocking stream is not ordered behind the null stream) waits
+  // for this event first (render_levels)
+  HIPCHK(hipEventRecord(c->upload_ev, nullptr));
   c->built = need;
   c->have_scene = true;
   rtow_build_info_t &bi = c->build_info;
@@ -912,14 +934,17 @@ static int sched_chunk_for(const rtow_ctx *c) {
   return mesh ? c->knobs.sched_chunk_mesh : c->knobs.sched_chunk;
 }
 struct LevelPlan {
-  int spt;    // samples per level
-  int first;  // index of the first level: its first sample is first * spt
-  int count;  // levels
+  int spt;             // samples per level
+  int first;           // index of the first level when the levels are the config's streams (strict build)
+  int count;           // levels
+  long long base;      // sample index of the first sample of level 0: level k covers [base + k * spt, ...)
+  int last;            // samples of the LAST level (= spt, or spt <= last < 2 spt when the schedule is ragged)
+  long long samples() const { return count > 0 ? (long long)(count - 1) * spt + last : 0; }
 };
 static LevelPlan level_plan(const rtow_config_t *cfg, int chunk) {
   const int spt = cfg->samples_per_pixel / cfg->nstreams;  // src/render.cpp:174
   const int streams_now = cfg->stream_count > 0 ? cfg->stream_count : cfg->nstreams;
-  LevelPlan p{spt, cfg->stream_first, streams_now};
+  LevelPlan p{spt, cfg->stream_first, streams_now, (long long)cfg->stream_first * spt, spt};
   if (cfg->precision == RTOW_F64_STRICT || chunk <= 0 || spt <= 0) return p;
   // a level length d must divide the first sample index and the number of samples: any divisor of their gcd
   const long long s0 = (long long)cfg->stream_first * spt, total = (long long)streams_now * spt;
@@ -941,10 +966,26 @@ static LevelPlan level_plan(const rtow_config_t *cfg, int chunk) {
       }
     }
   }
+  if (2 * best < chunk || best > 2LL * chunk) {
+    // No divisor within a factor of two of the aimed-at length (a prime sample count: 101 would be 101 levels of
+    // one sample — 101 work items and 101 partial images per pixel — or one level of 101).  Ragged schedule
+    // instead: levels of `chunk` samples from the first sample on, the remainder added to the LAST level
+    // (chunk <= last < 2 chunk; a range shorter than a chunk is one level).  Still a pure function of the config.
+    const long long n = std::max<long long>(total / chunk, 1);
+    if (n > 0x7fffffffLL) return p;
+    p.spt = n > 1 ? chunk : (int)total;
+    p.count = (int)n;
+    p.last = (int)(total - (n - 1) * (long long)p.spt);
+    p.base = s0;
+    p.first = 0;
+    return p;
+  }
   if (total / best > 0x7fffffffLL || best > 0x7fffffffLL) return p;
   p.spt = (int)best;
   p.first = (int)(s0 / best);
   p.count = (int)(total / best);
+  p.last = p.spt;
+  p.base = s0;
   return p;
 }
 
@@ -956,14 +997,34 @@ static int impl_debug_schedule(rtow_ctx *c, const rtow_config_t *cfg, uint32_t *
   if (!c) defaults.read();
   const LevelPlan p = level_plan(cfg, c ? sched_chunk_for(c) : defaults.sched_chunk);
   for (int i = 0; i < p.count && i < capacity_pairs && out; ++i) {
-    out[2 * i] = (uint32_t)(p.first + i) * (uint32_t)p.spt;
-    out[2 * i + 1] = (uint32_t)p.spt;
+    out[2 * i] = (uint32_t)(p.base + (long long)i * p.spt);
+    out[2 * i + 1] = (uint32_t)(i + 1 == p.count ? p.last : p.spt);
   }
   return p.count;
 }
 
 static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
                          rtow_stats_t *stats, const LevelPlan &plan, int lvl_first, int lvl_count, int accumulate);
+
+// Samples given up at the end-of-launch bound are an ERROR, never a darker image: the kernels count them in a device
+// word no launch resets.  Entry points that wait for the device anyway read it: `mirrored` = the word was copied to
+// c->h_dropped by a copy queued behind the render on a stream the caller has since waited for; otherwise it is read
+// with a blocking copy (the launches in question must have completed).
+static int check_dropped(rtow_ctx *c, bool mirrored) {
+  unsigned long long v = 0ull;
+  if (mirrored)
+    v = *c->h_dropped;
+  else
+    HIPCHK(hipMemcpy(&v, c->dropped.p, sizeof v, hipMemcpyDeviceToHost));
+  if (v == 0ull) return RTOW_OK;
+  *c->h_dropped = 0ull;
+  HIPCHK(hipMemset(c->dropped.p, 0, sizeof v));
+  return fail(RTOW_EHIP, "trace kernel: end-of-launch bound reached, %llu lanes gave up their samples", v);
+}
+static int mirror_dropped(rtow_ctx *c, hipStream_t st) {
+  HIPCHK(hipMemcpyAsync(c->h_dropped, c->dropped.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  return RTOW_OK;
+}
 
 static int impl_render_device(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
                        rtow_stats_t *stats) {
@@ -1026,6 +1087,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   const unsigned long long npix = (unsigned long long)rows * cfg->image_width;
   const int streams_now = lvl_count;  // levels of this launch
   const int spt = plan.spt;
+  const int spt_last = lvl_first + lvl_count == plan.count ? plan.last : plan.spt;  // (a ragged schedule ends on a longer level)
   const unsigned long long n_items = npix * (unsigned long long)streams_now;
   if (n_items > 0xfffffff0ULL) return fail(RTOW_EINVAL, "too many work items (%llu)", n_items);
   int kernel = cfg->kernel;
@@ -1180,6 +1242,16 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   P.spt = spt;
   P.nstreams = streams_now;
   P.stream_first = plan.first + lvl_first;
+  P.sample_base = (uint32_t)(plan.base + (long long)lvl_first * spt);
+  P.spt_last = spt_last;
+  {
+    // structural bound of the end-of-launch protocol (rtow_trace_body.h): x64 because a stopped-and-resumed walk
+    // spreads one segment over several trips
+    const unsigned long long b = 64ull * (4096ull + 8ull * (unsigned long long)(cfg->max_child_rays + 2) *
+                                                        (unsigned long long)(std::max(spt, spt_last) + 1));
+    P.tail_bound = c->knobs.tail_bound > 0 ? (uint32_t)c->knobs.tail_bound : (uint32_t)std::min<unsigned long long>(b, 0xfffffff0ull);
+  }
+  P.dropped = (unsigned long long *)c->dropped.p;
   P.max_child_rays = cfg->max_child_rays;
   P.rank = cfg->rank;
   P.nranks = cfg->nranks;
@@ -1245,6 +1317,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   P.counters = (unsigned long long *)c->counters.p;
   P.t_origin = P.counters + 16;
 
+  if (st != nullptr) HIPCHK(hipStreamWaitEvent(st, c->upload_ev, 0));  // the scene upload was queued on the null stream
   if (stats) HIPCHK(hipEventRecord(c->call_ev[0], st));
   if (!c->counters_init.p) {  // zeros, except the two minima of the diagnostic build ([5] min end, [16] t_origin)
     std::vector<unsigned long long> init(48, 0ull);
@@ -1301,9 +1374,11 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
     HIPCHK(hipMemcpyAsync(c->h_counters, c->counters.p, 48 * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (c->h_counters[47] != 0ull)  // the structural bound of the end-of-launch protocol fired (never observed)
+    if (c->h_counters[47] != 0ull) {  // the structural bound of the end-of-launch protocol fired (never observed)
+      (void)check_dropped(c, false);    // (clears the sticky word: this call reports the error)
       return fail(RTOW_EHIP, "trace kernel: end-of-launch bound reached, %llu lanes gave up their samples",
                   c->h_counters[47]);
+    }
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, c->call_ev[0], c->call_ev[1]));
     stats->total_ms = ms;
@@ -1311,7 +1386,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
       HIPCHK(hipEventElapsedTime(&ms, c->ev[slot][0], c->ev[slot][1]));
       stats->kernel_ms = ms;
     }
-    stats->samples = npix * (unsigned long long)spt * (unsigned long long)streams_now;
+    stats->samples = npix * ((unsigned long long)spt * (unsigned long long)(streams_now - 1) + (unsigned long long)spt_last);
     stats->segments = c->h_counters[1];
     if (kernel == RTOW_KERNEL_BRUTE) {
       stats->prim_tests = stats->segments * (unsigned long long)c->n_prims;
@@ -1384,8 +1459,11 @@ int rtow_profile_collect(rtow_ctx *c, double *kernel_ms_sum, int32_t *launches) 
   }
   if (kernel_ms_sum) *kernel_ms_sum = sum;
   if (launches) *launches = c->ev_count;
+  const bool waited = c->ev_count > 0;
   c->ev_count = 0;
-  return RTOW_OK;
+  // the asynchronous entry point (rtow_render_device without stats) reports dropped samples here: every launch
+  // of the ring has completed
+  return waited ? check_dropped(c, false) : RTOW_OK;
 }
 
 // Upload for ONE render whose config is known: only what its kernel reads (the cover scene through the grid
@@ -1433,7 +1511,37 @@ static int impl_render(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config
   if (cfg->accumulate)  // continue from the caller's sums
     HIPCHK(hipMemcpy(d_out, rgb_sums_host, bytes, hipMemcpyHostToDevice));
   rc = rtow_render_device(c, cfg, d_out, nullptr, stats);  // (no stats: no host wait before the copy below)
-  if (rc == RTOW_OK) HIPCHK(hipMemcpy(rgb_sums_host, d_out, bytes, hipMemcpyDeviceToHost));
+  if (rc != RTOW_OK) return rc;
+  if ((rc = mirror_dropped(c, nullptr))) return rc;
+  HIPCHK(hipMemcpy(rgb_sums_host, d_out, bytes, hipMemcpyDeviceToHost));
+  return check_dropped(c, true);  // never RTOW_OK with samples dropped, with or without `stats`
+}
+
+// This rank's rows as 8-bit RGB on the DEVICE: render + write_color (fused into the reduce kernel when the render is
+// one launch), asynchronous on `hip_stream` like rtow_render_device.  The f64 sums live in the context's workspace.
+static int impl_render_device_rgb8(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb8, void *hip_stream,
+                                   rtow_stats_t *stats) {
+  if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
+  if (!d_rgb8) return fail(RTOW_EINVAL, "d_rgb8 is NULL");
+  int rc = validate_cfg(cfg);
+  if (rc) return rc;
+  const int spp_eff = cfg->samples_per_pixel / cfg->nstreams * cfg->nstreams;  // src/render.cpp:185
+  if (spp_eff <= 0) return fail(RTOW_EINVAL, "no effective samples (samples_per_pixel < nstreams)");
+  if (cfg->accumulate) return fail(RTOW_EINVAL, "the rgb8 entry points own their sums: accumulate must be 0");
+  const int rows = rtow_local_rows(cfg);
+  const size_t n = (size_t)rows * cfg->image_width * 3;
+  if (n == 0) {
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    return RTOW_OK;
+  }
+  HIPCHK(hipSetDevice(c->device));
+  if ((rc = c->out.ensure(n * sizeof(double)))) return rc;  // kept across calls
+  c->fuse_rgb8 = (unsigned char *)d_rgb8;  // write_color inside the reduce kernel when the render is one launch
+  c->fuse_spp = (double)spp_eff;
+  c->fuse_used = false;
+  rc = impl_render_device(c, cfg, c->out.p, hip_stream, stats);
+  c->fuse_rgb8 = nullptr;
+  if (rc == RTOW_OK && !c->fuse_used) rc = rtow_tonemap_device(c, c->out.p, (int64_t)n, spp_eff, d_rgb8, hip_stream);
   return rc;
 }
 
@@ -1445,8 +1553,7 @@ static int impl_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_c
   if (!rgb8_host) return fail(RTOW_EINVAL, "rgb8_host is NULL");
   int rc = validate_cfg(cfg);
   if (rc) return rc;
-  const int spp_eff = cfg->samples_per_pixel / cfg->nstreams * cfg->nstreams;  // src/render.cpp:185
-  if (spp_eff <= 0) return fail(RTOW_EINVAL, "no effective samples (samples_per_pixel < nstreams)");
+  if (cfg->samples_per_pixel / cfg->nstreams <= 0) return fail(RTOW_EINVAL, "no effective samples (samples_per_pixel < nstreams)");
   if (cfg->accumulate) return fail(RTOW_EINVAL, "rtow_render_rgb8 owns its sums: accumulate must be 0");
   if ((rc = upload_for(c, scene, cfg))) return rc;
   const int rows = rtow_local_rows(cfg);
@@ -1455,18 +1562,13 @@ static int impl_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_c
     if (stats) std::memset(stats, 0, sizeof *stats);
     return RTOW_OK;
   }
-  if ((rc = c->out.ensure(n * sizeof(double))) || (rc = c->out8.ensure(n))) return rc;  // kept across calls
-  c->fuse_rgb8 = (unsigned char *)c->out8.p;  // write_color inside the reduce kernel when the render is one launch
-  c->fuse_spp = (double)spp_eff;
-  c->fuse_used = false;
-  rc = rtow_render_device(c, cfg, c->out.p, nullptr, stats);
-  c->fuse_rgb8 = nullptr;
-  if (rc == RTOW_OK && !c->fuse_used) rc = rtow_tonemap_device(c, c->out.p, (int64_t)n, spp_eff, c->out8.p, nullptr);
-  if (rc != RTOW_OK) return rc;
+  if ((rc = c->out8.ensure(n))) return rc;  // kept across calls
+  if ((rc = impl_render_device_rgb8(c, cfg, c->out8.p, nullptr, stats))) return rc;
   // (a pinned landing buffer + host memcpy measured slower than the runtime's own staged copy for these 2.9 MB:
   // 8.67 vs 8.55 ms per call)
+  if ((rc = mirror_dropped(c, nullptr))) return rc;
   HIPCHK(hipMemcpy(rgb8_host, c->out8.p, n, hipMemcpyDeviceToHost));
-  return RTOW_OK;
+  return check_dropped(c, true);  // never RTOW_OK with samples dropped, with or without `stats`
 }
 
 // ---- the guarded entry points (see guarded() above) ----
@@ -1487,9 +1589,17 @@ int rtow_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t
                      rtow_stats_t *stats) {
   return guarded("rtow_render_rgb8", [&] { return impl_render_rgb8(c, scene, cfg, rgb8_host, stats); });
 }
+int rtow_render_device_rgb8(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb8, void *hip_stream, rtow_stats_t *stats) {
+  return guarded("rtow_render_device_rgb8", [&] { return impl_render_device_rgb8(c, cfg, d_rgb8, hip_stream, stats); });
+}
 int rtow_debug_schedule(rtow_ctx *c, const rtow_config_t *cfg, uint32_t *out, int32_t capacity_pairs) {
   return guarded("rtow_debug_schedule", [&] { return impl_debug_schedule(c, cfg, out, capacity_pairs); });
 }
 
 }  // extern "C"
+
+namespace rtow {
+// for rtow_multi.cpp: the sticky dropped-samples word of a context, read after its stream has been waited for
+int ctx_check_dropped(rtow_ctx *c) { return c ? check_dropped(c, false) : RTOW_OK; }
+}  // namespace rtow
 

@@ -97,7 +97,11 @@ struct TraceParams {
   // launch's sample range is cut into levels by the host (rtow_capi.cpp, level_plan) whatever nstreams is.
   int32_t spt;             // samples per level
   int32_t nstreams;        // levels traced by THIS launch
-  int32_t stream_first;    // index of its first level (sample index = level * spt + s)
+  int32_t stream_first;    // index of its first level (strict build: sample_base = stream_first * spt)
+  uint32_t sample_base;    // sample index of the first sample of this launch's level 0 (level k starts at sample_base + k * spt)
+  int32_t spt_last;        // samples of the launch's LAST level (= spt unless the host's schedule ends on a longer one:
+                           // a sample count with no divisor near the aimed-at item length, rtow_capi.cpp level_plan)
+  uint32_t tail_bound;     // trips a wave may spend in the end-of-launch protocol before it gives up (structural bound)
   int32_t max_child_rays;
   int32_t rank, nranks, tile_rows;
   int32_t local_rows;
@@ -121,6 +125,8 @@ struct TraceParams {
   uint32_t walk_cap, walk_max_open;  // GRID / BVH4 walks: resumable walk (rtow_trace_grid.h); cap 0xffffffff = never stop
   uint32_t sm4_restart, sm4_scatter, sm4_leaf;  // state machine: lanes that must wait for a block before it runs
   unsigned long long *counters; // [0] next item, [1] segments, [2] prim tests, [3] node tests
+  unsigned long long *dropped;  // sticky (never reset by a launch): lanes that gave up samples at the tail bound; the
+                                // host turns a non-zero word into RTOW_EHIP at its next synchronising entry point
   unsigned long long *t_origin; // diagnostic build: earliest wave start (100 MHz clock)
 };
 
@@ -149,5 +155,8 @@ int trace_occupancy_fast(int kernel, int block, unsigned lds_bytes);
 int trace_occupancy_f32(int kernel, int block, unsigned lds_bytes);
 int launch_reduce(const ReduceParams &p, void *stream);
 int launch_tonemap(const double *sums, unsigned char *rgb8, uint32_t n, double spp, void *stream);
+// rtow_reduce.hip: [rank][max_rows][row_bytes] (what one gather delivers) -> [height][row_bytes] in global row order
+int launch_place_rows(const void *gathered, void *image, uint32_t n_ranks, uint32_t max_rows, uint32_t row_bytes,
+                      uint32_t height, uint32_t tile_rows, void *stream);
 
 }  // namespace rtow

@@ -5,11 +5,13 @@
 // launch order (src/render.cpp:169-180).  Here a worker is a device: one host thread and one
 // context per device, the image cut into strips of cfg->tile_rows rows dealt round-robin (the
 // partition of include/rtow.h, rank = position in `device_ids`), every device traces its strips
-// into a [max_rows][W][3] f64 buffer, and ONE ncclGather (RCCL over xGMI), enqueued on each rank's
-// stream right behind its trace kernel, brings the buffers to the first device, from where ONE
-// device-to-host copy delivers them; the host then puts every strip row in its place.  Any N gives
-// the one-device image bit for bit (a pixel's value does not depend on who traces it:
-// counter-based RNG, fixed sample order).
+// into a [max_rows][W][3] buffer — f64 radiance sums (rtow_multi_render) or, with write_color run by the rank that
+// owns the pixel (rtow_multi_render_rgb8; src/render.cpp:11-20,182-186), the 8-bit values of the PPM — and ONE
+// ncclGather (RCCL over xGMI), enqueued on each rank's stream right behind its trace kernel, brings the buffers to
+// the first device.  There a small kernel puts every strip row in its place (csrc/rtow_reduce.hip, rtow_place_rows)
+// and ONE device-to-host copy delivers the finished image straight into the caller's buffer: no host pass over the
+// pixels.  Any N gives the one-device image bit for bit (a pixel's value does not depend on who traces it:
+// counter-based RNG, fixed sample order; every pixel has one owner, so its byte is the owner's byte).
 //
 // What lives in the handle, created once (rtow_multi_create) and reused by every frame: the
 // contexts (with their scene images and workspaces), one stream per device, the strip buffers,
@@ -36,6 +38,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -48,6 +51,9 @@
 
 namespace rtow {
 int set_last_error(int code, const char *fmt, ...);  // rtow_capi.cpp
+int ctx_check_dropped(rtow_ctx *c);                  // rtow_capi.cpp: samples given up at the end-of-launch bound
+int launch_place_rows(const void *gathered, void *image, uint32_t n_ranks, uint32_t max_rows, uint32_t row_bytes,
+                      uint32_t height, uint32_t tile_rows, void *stream);  // rtow_reduce.hip
 }
 
 namespace {
@@ -56,6 +62,7 @@ struct Rccl {
   void *lib = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
   decltype(&ncclGather) Gather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool load(std::string &why) {
@@ -69,9 +76,10 @@ struct Rccl {
     }
     CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    CommAbort = (decltype(CommAbort))dlsym(lib, "ncclCommAbort");
     Gather = (decltype(Gather))dlsym(lib, "ncclGather");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!CommInitAll || !CommDestroy || !Gather || !GetErrorString) {
+    if (!CommInitAll || !CommDestroy || !CommAbort || !Gather || !GetErrorString) {
       why = "librccl.so lacks ncclCommInitAll / ncclGather";
       return false;
     }
@@ -83,8 +91,9 @@ struct Rank {
   int device = 0;
   rtow_ctx *ctx = nullptr;
   hipStream_t stream = nullptr;
-  void *d_local = nullptr;   // this rank's strips: [max_rows][W][3] f64
+  void *d_local = nullptr;   // this rank's strips: [max_rows][W][3] f64 sums or bytes
   size_t local_bytes = 0;
+  hipEvent_t strips_ev = nullptr;  // use_rccl == 0: this rank's copy into the first device's gather buffer has been queued
   ncclComm_t comm = nullptr;
   int err = RTOW_OK;
   std::string msg;
@@ -127,8 +136,10 @@ struct rtow_multi {
   std::vector<Rank> ranks;
   void *d_gather = nullptr;  // on the first device: [rank][max_rows][W][3]
   size_t gather_bytes = 0;
-  double *h_staging = nullptr;  // pinned: what the one device-to-host copy (or the ranks' own copies) fills
-  size_t staging_bytes = 0;
+  void *d_image = nullptr;   // on the first device: [H][W][3], rows in place — what the one device-to-host copy reads
+  size_t image_bytes = 0;
+  bool comm_dead = false;    // a collective failed half-issued and the communicators were aborted: the handle renders no more
+  int fail_gather_rank = -1; // RTOW_MULTI_FAIL_GATHER (tests): this rank's gather enqueue reports a failure without enqueuing
   // workers
   std::vector<std::thread> threads;
   std::mutex mu;
@@ -204,11 +215,12 @@ void rtow_multi_destroy(rtow_multi *m) {
     if (k.stream) (void)hipStreamSynchronize(k.stream);
     if (k.d_local) (void)hipFree(k.d_local);
     if (r == 0 && m->d_gather) (void)hipFree(m->d_gather);
+    if (r == 0 && m->d_image) (void)hipFree(m->d_image);
+    if (k.strips_ev) (void)hipEventDestroy(k.strips_ev);
     if (k.comm) (void)m->rccl.CommDestroy(k.comm);
     if (k.stream) (void)hipStreamDestroy(k.stream);
     rtow_ctx_destroy(k.ctx);
   }
-  if (m->h_staging) (void)hipHostFree(m->h_staging);
   if (m->rccl.lib) dlclose(m->rccl.lib);
   delete m;
 }
@@ -242,13 +254,20 @@ int rtow_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_
       }
       for (int r = 0; r < n_devices; ++r) m->ranks[(size_t)r].comm = comms[(size_t)r];
     }
-    for (int r = 0; r < n_devices; ++r) m->threads.emplace_back([m, r] { m->worker(r); });
+    if (const char *e = std::getenv("RTOW_MULTI_FAIL_GATHER")) m->fail_gather_rank = std::atoi(e);
+    try {
+      for (int r = 0; r < n_devices; ++r) m->threads.emplace_back([m, r] { m->worker(r); });
+    } catch (...) {  // a thread could not be started: the ones that run are joined by destroy
+      rtow_multi_destroy(m);
+      throw;
+    }
     m->run([m](int r) {
       Rank &me = m->ranks[(size_t)r];
       const int rc = rtow_ctx_create(me.device, &me.ctx);
       if (rc) return me.fail_with_last(rc, "rtow_ctx_create");
       if (!me.hip(hipSetDevice(me.device), "hipSetDevice")) return;
-      me.hip(hipStreamCreate(&me.stream), "hipStreamCreate");
+      if (!me.hip(hipStreamCreate(&me.stream), "hipStreamCreate")) return;
+      me.hip(hipEventCreateWithFlags(&me.strips_ev, hipEventDisableTiming), "hipEventCreate");
     });
     const int rc = m->collect("rtow_multi_create");
     if (rc) {
@@ -290,35 +309,49 @@ int rtow_multi_build_info(rtow_multi *m, rtow_build_info_t *out) {
   return rtow_build_info(m->ranks[0].ctx, out);  // every device builds the same structures
 }
 
-int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats) {
-  if (!m || !cfg || !rgb_sums_host) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_render: NULL argument");
-  if (!m->have_scene) return rtow::set_last_error(RTOW_ENOSCENE, "rtow_multi_render: no scene uploaded");
-  if (cfg->accumulate) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_render: accumulate is not supported");
-  return guarded("rtow_multi_render", [&]() -> int {
+// One frame.  rgb8 == false: W*H*3 f64 radiance sums; true: W*H*3 bytes, write_color by the owning rank.
+static int multi_render(rtow_multi *m, const rtow_config_t *cfg, void *host_out, rtow_stats_t *stats, bool rgb8) {
+  const char *what = rgb8 ? "rtow_multi_render_rgb8" : "rtow_multi_render";
+  if (!m || !cfg || !host_out) return rtow::set_last_error(RTOW_EINVAL, "%s: NULL argument", what);
+  if (!m->have_scene) return rtow::set_last_error(RTOW_ENOSCENE, "%s: no scene uploaded", what);
+  if (cfg->accumulate) return rtow::set_last_error(RTOW_EINVAL, "%s: accumulate is not supported", what);
+  if (m->comm_dead)
+    return rtow::set_last_error(RTOW_EHIP, "%s: the communicators of this handle were aborted after a failed collective; "
+                                           "create a new handle", what);
+  return guarded(what, [&]() -> int {
     const int n = m->n;
     rtow_config_t probe = *cfg;
     probe.rank = 0;
     probe.nranks = n;
     const int max_rows = rtow_local_rows(&probe);  // rank 0 owns the first strip: nobody has more rows
     if (max_rows < 0) return max_rows;
-    const int W = cfg->image_width;
-    const size_t count = (size_t)max_rows * (size_t)W * 3;  // doubles per rank in the gather
+    const int W = cfg->image_width, H = cfg->image_height;
+    const size_t es = rgb8 ? 1 : sizeof(double);
+    const size_t count = (size_t)max_rows * (size_t)W * 3;  // values per rank in the gather
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (count == 0) return RTOW_OK;
-    const size_t bytes = count * sizeof(double);
-    // buffers of the handle, grown on demand (a frame of the same shape allocates nothing)
-    if (m->staging_bytes < (size_t)n * bytes) {
-      if (m->h_staging) (void)hipHostFree(m->h_staging);
-      m->h_staging = nullptr;
-      m->staging_bytes = 0;
-      (void)hipSetDevice(m->ranks[0].device);
-      const hipError_t e = hipHostMalloc((void **)&m->h_staging, (size_t)n * bytes, hipHostMallocPortable);
-      if (e != hipSuccess) return rtow::set_last_error(RTOW_EHIP, "hipHostMalloc of the staging buffer: %s", hipGetErrorString(e));
-      m->staging_bytes = (size_t)n * bytes;
+    const size_t bytes = count * es, row_bytes = (size_t)W * 3 * es, image_bytes = (size_t)H * row_bytes;
+    // buffers of the handle on the first device, grown on demand (a frame of the same shape allocates nothing)
+    {
+      Rank &r0 = m->ranks[0];
+      hipError_t e = hipSetDevice(r0.device);
+      if (e == hipSuccess && m->gather_bytes < (size_t)n * bytes) {
+        if (m->d_gather) (void)hipFree(m->d_gather);
+        m->d_gather = nullptr;
+        m->gather_bytes = 0;
+        if ((e = hipMalloc(&m->d_gather, (size_t)n * bytes)) == hipSuccess) m->gather_bytes = (size_t)n * bytes;
+      }
+      if (e == hipSuccess && m->image_bytes < image_bytes) {
+        if (m->d_image) (void)hipFree(m->d_image);
+        m->d_image = nullptr;
+        m->image_bytes = 0;
+        if ((e = hipMalloc(&m->d_image, image_bytes)) == hipSuccess) m->image_bytes = image_bytes;
+      }
+      if (e != hipSuccess) return rtow::set_last_error(RTOW_EHIP, "%s: buffers on device %d: %s", what, r0.device, hipGetErrorString(e));
     }
     const bool rccl = m->use_rccl;
     const bool want_stats = stats != nullptr;
-    m->run([m, cfg, n, count, bytes, rccl, want_stats](int r) {
+    m->run([m, cfg, n, count, bytes, rccl, want_stats, rgb8](int r) {
       Rank &me = m->ranks[(size_t)r];
       if (!me.hip(hipSetDevice(me.device), "hipSetDevice")) return;
       if (me.local_bytes < bytes) {
@@ -327,13 +360,6 @@ int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_
         me.local_bytes = 0;
         if (!me.hip(hipMalloc(&me.d_local, bytes), "hipMalloc")) return;
         me.local_bytes = bytes;
-      }
-      if (r == 0 && rccl && m->gather_bytes < (size_t)n * bytes) {
-        if (m->d_gather) (void)hipFree(m->d_gather);
-        m->d_gather = nullptr;
-        m->gather_bytes = 0;
-        if (!me.hip(hipMalloc(&m->d_gather, (size_t)n * bytes), "hipMalloc")) return;
-        m->gather_bytes = (size_t)n * bytes;
       }
       rtow_config_t mine = *cfg;
       mine.rank = r;
@@ -345,36 +371,72 @@ int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_
           !me.hip(hipMemsetAsync(me.d_local, 0, bytes, me.stream), "hipMemsetAsync"))
         return;
       if (rows > 0) {
-        const int rc = rtow_render_device(me.ctx, &mine, me.d_local, me.stream, want_stats ? &me.stats : nullptr);
-        if (rc) return me.fail_with_last(rc, "rtow_render_device");
+        const int rc = rgb8 ? rtow_render_device_rgb8(me.ctx, &mine, me.d_local, me.stream, want_stats ? &me.stats : nullptr)
+                            : rtow_render_device(me.ctx, &mine, me.d_local, me.stream, want_stats ? &me.stats : nullptr);
+        if (rc) return me.fail_with_last(rc, rgb8 ? "rtow_render_device_rgb8" : "rtow_render_device");
       }
-      if (!rccl) {  // every device delivers its own strips
-        me.hip(hipMemcpyAsync(m->h_staging + (size_t)r * count, me.d_local, bytes, hipMemcpyDeviceToHost, me.stream),
-               "hipMemcpyAsync");
+      if (!rccl) {
+        // no collective (ranks on one device, where a communicator cannot exist): every rank copies its strips into
+        // its slot of the first device's gather buffer and marks the copy on its stream
+        unsigned char *slot = (unsigned char *)m->d_gather + (size_t)r * bytes;
+        const int dev0 = m->ranks[0].device;
+        if (!me.hip(me.device == dev0 ? hipMemcpyAsync(slot, me.d_local, bytes, hipMemcpyDeviceToDevice, me.stream)
+                                      : hipMemcpyPeerAsync(slot, dev0, me.d_local, me.device, bytes, me.stream),
+                    "copy of the strips to the first device"))
+          return;
+        me.hip(hipEventRecord(me.strips_ev, me.stream), "hipEventRecord");
       }
     });
-    int rc = m->collect("rtow_multi_render");
+    int rc = m->collect(what);
     if (rc == RTOW_OK && rccl) {
       // the one collective, stream-ordered behind every rank's kernels: each rank's strip buffer to the first
       // device.  One thread per device calls ncclGather on its own communicator and stream (the calls of a
-      // collective may come from different threads; each enqueues on its own stream).  Rank 0 then enqueues
-      // the one device-to-host copy behind its side of the gather.
-      m->run([m, count](int r) {
+      // collective may come from different threads; each enqueues on its own stream).
+      m->run([m, count, rgb8](int r) {
         Rank &me = m->ranks[(size_t)r];
         if (!me.hip(hipSetDevice(me.device), "hipSetDevice")) return;
-        const ncclResult_t res = m->rccl.Gather(me.d_local, r == 0 ? m->d_gather : nullptr, count, ncclDouble, 0, me.comm, me.stream);
+        const ncclResult_t res = r == m->fail_gather_rank
+                                     ? ncclInternalError  // (test hook: this rank's side of the collective is never enqueued)
+                                     : m->rccl.Gather(me.d_local, r == 0 ? m->d_gather : nullptr, count, rgb8 ? ncclUint8 : ncclDouble,
+                                                      0, me.comm, me.stream);
         if (res != ncclSuccess) {
           me.err = RTOW_EHIP;
           me.msg = std::string("ncclGather: ") + m->rccl.GetErrorString(res);
-          return;
         }
-        if (r == 0)
-          me.hip(hipMemcpyAsync(m->h_staging, m->d_gather, (size_t)m->n * count * sizeof(double), hipMemcpyDeviceToHost, me.stream),
-                 "hipMemcpyAsync of the gathered strips");
       });
-      rc = m->collect("rtow_multi_render (gather)");
+      rc = m->collect(rgb8 ? "rtow_multi_render_rgb8 (gather)" : "rtow_multi_render (gather)");
+      if (rc != RTOW_OK) {
+        // A collective that one rank could not enqueue never completes on the ranks that did: waiting for their
+        // streams would hang.  Abort every communicator (in-flight kernels exit), do not wait, and refuse further
+        // frames on this handle: the error is an error code, never a wait.
+        const std::string keep = rtow_last_error();
+        for (Rank &k : m->ranks) {
+          if (k.comm) {
+            (void)hipSetDevice(k.device);
+            (void)m->rccl.CommAbort(k.comm);
+            k.comm = nullptr;
+          }
+        }
+        m->comm_dead = true;
+        return rtow::set_last_error(rc, "%s (communicators aborted)", keep.c_str());
+      }
     }
-    // wait for every stream (the copies above are the last thing on them)
+    if (rc == RTOW_OK) {
+      // on the first device, behind the strips' arrival: rows into place, then the ONE device-to-host copy, straight
+      // into the caller's buffer
+      Rank &r0 = m->ranks[0];
+      hipError_t e = hipSetDevice(r0.device);
+      if (!rccl)
+        for (int r = 1; r < n && e == hipSuccess; ++r) e = hipStreamWaitEvent(r0.stream, m->ranks[(size_t)r].strips_ev, 0);
+      if (e == hipSuccess) {
+        const int lrc = rtow::launch_place_rows(m->d_gather, m->d_image, (uint32_t)n, (uint32_t)max_rows, (uint32_t)row_bytes,
+                                                (uint32_t)H, (uint32_t)cfg->tile_rows, r0.stream);
+        if (lrc != 0) e = (hipError_t)lrc;
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(host_out, m->d_image, image_bytes, hipMemcpyDeviceToHost, r0.stream);
+      if (e != hipSuccess) rc = rtow::set_last_error(RTOW_EHIP, "%s: placement / copy on device %d: %s", what, r0.device, hipGetErrorString(e));
+    }
+    // wait for every stream (the first device's copy is the last thing queued)
     for (int r = 0; r < n; ++r) {
       Rank &me = m->ranks[(size_t)r];
       (void)hipSetDevice(me.device);
@@ -383,17 +445,9 @@ int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_
         rc = rtow::set_last_error(RTOW_EHIP, "rank %d (device %d): hipStreamSynchronize: %s", r, me.device, hipGetErrorString(e));
     }
     if (rc != RTOW_OK) return rc;
-    // strips back to their rows: rank r's i-th local row is global row rows_r[i]
-    const size_t row_values = (size_t)W * 3;
-    std::vector<int32_t> row_ids((size_t)std::max(max_rows, 1));
-    for (int r = 0; r < n; ++r) {
-      rtow_config_t mine = *cfg;
-      mine.rank = r;
-      mine.nranks = n;
-      const int rows = rtow_local_row_list(&mine, row_ids.data(), max_rows);
-      for (int i = 0; i < rows; ++i)
-        std::memcpy(rgb_sums_host + (size_t)row_ids[(size_t)i] * row_values, m->h_staging + (size_t)r * count + (size_t)i * row_values,
-                    row_values * sizeof(double));
+    for (int r = 0; r < n; ++r) {  // never RTOW_OK with samples dropped (the end-of-launch bound of the trace kernel)
+      (void)hipSetDevice(m->ranks[(size_t)r].device);
+      if ((rc = rtow::ctx_check_dropped(m->ranks[(size_t)r].ctx))) return rc;
     }
     if (stats) {
       for (int r = 0; r < n; ++r) {
@@ -410,6 +464,16 @@ int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_
     }
     return RTOW_OK;
   });
+}
+
+int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats) {
+  return multi_render(m, cfg, rgb_sums_host, stats, false);
+}
+
+int rtow_multi_render_rgb8(rtow_multi *m, const rtow_config_t *cfg, unsigned char *rgb8_host, rtow_stats_t *stats) {
+  if (cfg && cfg->nstreams > 0 && cfg->samples_per_pixel / cfg->nstreams <= 0)
+    return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_render_rgb8: no effective samples (samples_per_pixel < nstreams)");
+  return multi_render(m, cfg, rgb8_host, stats, true);
 }
 
 // The one-shot form: everything above for a single frame (set-up dominates it: use the handle for more than one).

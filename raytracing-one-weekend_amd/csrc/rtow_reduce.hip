@@ -44,7 +44,43 @@ __global__ void __launch_bounds__(256) rtow_tonemap_u8(const double *sums, unsig
   const int v = (int)(256.0 * c);
   rgb8[idx] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
+// Strips back to their rows, on the device (the multi-GPU output path, rtow_multi.cpp): `gathered` is
+// [rank][max_rows][row_words] as one gather delivers it; global row i belongs to strip t = i / tile_rows, rank t % n,
+// and is that rank's local row (t / n) * tile_rows + i % tile_rows.  One thread per word of the image.
+template <class Word>
+__global__ void __launch_bounds__(256) rtow_place_rows(const Word *gathered, Word *image, uint32_t n_ranks, uint32_t max_rows,
+                                                       uint32_t row_words, uint32_t height, uint32_t tile_rows) {
+  const uint32_t w = blockIdx.x * 256u + threadIdx.x, i = blockIdx.y;
+  if (w >= row_words || i >= height) return;
+  const uint32_t t = i / tile_rows, r = t % n_ranks;
+  const uint32_t lr = (t / n_ranks) * tile_rows + (i - t * tile_rows);
+  image[(size_t)i * row_words + w] = gathered[((size_t)r * max_rows + lr) * row_words + w];
+}
 }  // namespace
+
+int launch_place_rows(const void *gathered, void *image, uint32_t n_ranks, uint32_t max_rows, uint32_t row_bytes,
+                      uint32_t height, uint32_t tile_rows, void *stream) {
+  if (row_bytes == 0 || height == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  // widest word that divides a row (rows of f64 sums: 8 bytes at least; W*3 bytes of an rgb8 row: often 16)
+  if (row_bytes % 16u == 0u) {
+    const uint32_t rw = row_bytes / 16u;
+    hipLaunchKernelGGL(rtow_place_rows<uint4>, dim3((rw + 255u) / 256u, height), dim3(256), 0, st, (const uint4 *)gathered,
+                       (uint4 *)image, n_ranks, max_rows, rw, height, tile_rows);
+  } else if (row_bytes % 8u == 0u) {
+    const uint32_t rw = row_bytes / 8u;
+    hipLaunchKernelGGL(rtow_place_rows<uint2>, dim3((rw + 255u) / 256u, height), dim3(256), 0, st, (const uint2 *)gathered,
+                       (uint2 *)image, n_ranks, max_rows, rw, height, tile_rows);
+  } else if (row_bytes % 4u == 0u) {
+    const uint32_t rw = row_bytes / 4u;
+    hipLaunchKernelGGL(rtow_place_rows<uint32_t>, dim3((rw + 255u) / 256u, height), dim3(256), 0, st, (const uint32_t *)gathered,
+                       (uint32_t *)image, n_ranks, max_rows, rw, height, tile_rows);
+  } else {
+    hipLaunchKernelGGL(rtow_place_rows<unsigned char>, dim3((row_bytes + 255u) / 256u, height), dim3(256), 0, st,
+                       (const unsigned char *)gathered, (unsigned char *)image, n_ranks, max_rows, row_bytes, height, tile_rows);
+  }
+  return (int)hipGetLastError();
+}
 
 int launch_tonemap(const double *sums, unsigned char *rgb8, uint32_t n, double spp, void *stream) {
   const unsigned grid = (n + 255u) / 256u;

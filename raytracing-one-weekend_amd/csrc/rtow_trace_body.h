@@ -177,6 +177,7 @@ __device__ __forceinline__ unsigned long long take_items(ItemPool &pool, unsigne
 // near ground, short paths — measures the same.)  The partial-sum slot stays [stream][pixel].
 struct ItemPos {
   uint32_t item, j, gi, sample0;
+  int32_t count;  // samples of the item (the launch's last level may be longer than the others)
 };
 __device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp, uint32_t mine, uint32_t npix_local) {
   ItemPos ip;
@@ -206,7 +207,8 @@ __device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp,
   const uint32_t q = fastdiv(lr, FastDiv{kp->div_tile.magic, kp->div_tile.shift});
   const uint32_t rr = lr - q * (uint32_t)kp->tile_rows;
   ip.gi = (q * (uint32_t)kp->nranks + (uint32_t)kp->rank) * (uint32_t)kp->tile_rows + rr;
-  ip.sample0 = (k + (uint32_t)kp->stream_first) * (uint32_t)kp->spt;  // first sample index of this stream
+  ip.sample0 = kp->sample_base + k * (uint32_t)kp->spt;  // first sample index of this level
+  ip.count = k + 1u == (uint32_t)kp->nstreams ? kp->spt_last : kp->spt;
   return ip;
 }
 
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
           gi = ip.gi;
           g.pixel = gi * (uint32_t)kp->W + j;
           g.sample = ip.sample0;
-          s_left = kp->spt;
+          s_left = ip.count;
           acc = {0.0, 0.0, 0.0};
         }
       }
@@ -557,8 +559,15 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       // structural bound on the tail (every wait above ends when a bounded path ends; this makes
       // the exit independent of that argument): give up donating, never hang
       // (x64: a stopped-and-resumed walk spreads one segment over several trips)
-      if (++tail_trips > 64u * (4096u + 8u * (uint32_t)(P.max_child_rays + 2) * (uint32_t)(P.spt + 1))) {
-        if (!done || holding) atomicAdd(&P.counters[47], 1ull);  // samples dropped: the host turns this into an error
+      // (the bound — 64 x (4096 + 8 (max_child_rays + 2)(longest item + 1)) trips — is computed by the host and read
+      // from the kernel-argument segment here, where it is needed: once per trip of a draining wave)
+      const RTOW_CONST TraceParams *kpt = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kpt));  // (opaque per trip, like kp above: the load must not be hoisted into an SGPR held across the loop)
+      if (++tail_trips > kpt->tail_bound) {
+        if (!done || holding) {  // samples dropped: the host turns this into an error (the word is sticky across launches)
+          atomicAdd(&P.counters[47], 1ull);
+          atomicAdd(kpt->dropped, 1ull);
+        }
         done = true;
         helping = false;
         holding = false;

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
               gi = ip.gi;
               g.pixel = gi * (uint32_t)kp->W + j;
               g.sample = ip.sample0;
-              s_left = kp->spt;
+              s_left = ip.count;
               acc = {0.0, 0.0, 0.0};
               phase = s_left > 0 ? PH_SAMPLE : PH_ITEM;
             }

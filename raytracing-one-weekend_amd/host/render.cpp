@@ -257,14 +257,12 @@ static void render_flat(FlatScene *flat, const Config &cfg) {
   rtow_build_info_t bi;
   std::memset(&bi, 0, sizeof bi);
   const int ngpus = std::max(opt.gpus, 1);
-  const int spp_eff_all = cfg.samples_per_pixel / cfg.nthreads * cfg.nthreads;
   if (ngpus > 1 || opt.rccl) {
     // several devices (or --rccl): rtow_render_multi — one host thread and context per device, strips dealt
     // round-robin, one ncclGather to the first device + one D2H (distinct devices), or one D2H per rank
     // (--gpus-same-device: RCCL cannot span a device twice)
     std::vector<int32_t> devs((size_t)ngpus);
     for (int r = 0; r < ngpus; ++r) devs[(size_t)r] = opt.gpus_same_device ? opt.device : opt.device + r;
-    std::vector<double> sums(nvalues);
     const int use_rccl = opt.gpus_same_device && ngpus > 1 ? 0 : 1;
     // RCCL prints a version banner on stdout when it initialises; stdout is the PPM (src/render.cpp:182-186),
     // so the banner is sent to stderr while the communicator is created (rtow_multi_create; nothing else of
@@ -283,7 +281,10 @@ static void render_flat(FlatScene *flat, const Config &cfg) {
     std::string msg = err == RTOW_OK ? std::string() : std::string(rtow_last_error());
     if (err == RTOW_OK && opt.builder >= 0 && (err = rtow_multi_set_builder(multi, opt.builder))) msg = rtow_last_error();
     if (err == RTOW_OK && nvalues) {
-      if ((err = rtow_multi_upload(multi, flat_view(flat))) || (err = rtow_multi_render(multi, &rc, sums.data(), &st)))
+      // --p6: write_color runs on the device of the rank that owns the pixel; bytes are gathered and copied
+      if ((err = rtow_multi_upload(multi, flat_view(flat))) ||
+          (err = opt.binary_ppm ? rtow_multi_render_rgb8(multi, &rc, rgb8.data(), &st)
+                                : rtow_multi_render(multi, &rc, image.data(), &st)))
         msg = rtow_last_error();
       else
         (void)rtow_multi_build_info(multi, &bi);
@@ -291,16 +292,6 @@ static void render_flat(FlatScene *flat, const Config &cfg) {
     rtow_multi_destroy(multi);
     flat_free(flat);
     if (err != RTOW_OK) throw std::runtime_error("HIP render failed (" + std::to_string(err) + "): " + msg);
-    if (opt.binary_ppm) {  // write_color on the host: the same correctly rounded operations as the device epilogue
-      for (size_t q = 0; q < nvalues; ++q) {
-        double c = std::sqrt(sums[q] / static_cast<double>(spp_eff_all));
-        c = c < 0.0 ? 0.0 : (c > 0.999 ? 0.999 : c);
-        const int v = static_cast<int>(256.0 * c);
-        rgb8[q] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
-      }
-    } else {
-      image.swap(sums);
-    }
   } else {
     rtow_ctx *ctx = nullptr;
     int err = rtow_ctx_create(opt.device, &ctx);

@@ -17,8 +17,8 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 LIB_PATH = Path(os.environ.get("RTOW_LIB", PKG_DIR / "librtow.so"))  # RTOW_LIB: A/B against another build
 
-RTOW_ABI_VERSION = 5
-RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY = 0, -1, -2, -3, -4, -5
+RTOW_ABI_VERSION = 6
+RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY, RTOW_ENOMEM = 0, -1, -2, -3, -4, -5, -6
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
 F64_STRICT, F64_FAST, F32 = 0, 1, 2
@@ -107,6 +107,7 @@ EXPORTS = [
     "rtow_debug_schedule", "rtow_host_scene_cover_model", "rtow_host_scene_obj_model",
     "rtow_multi_create", "rtow_multi_set_builder", "rtow_multi_upload", "rtow_multi_build_info",
     "rtow_multi_render", "rtow_multi_destroy", "rtow_host_reftree_info",
+    "rtow_render_device_rgb8", "rtow_multi_render_rgb8",
 ]
 
 
@@ -177,6 +178,11 @@ def lib():
         L.rtow_multi_render.argtypes = [C.c_void_p, C.POINTER(Config), _pd, C.POINTER(Stats)]
         L.rtow_multi_destroy.argtypes = [C.c_void_p]
         L.rtow_multi_destroy.restype = None
+    if hasattr(L, "rtow_multi_render_rgb8"):
+        L.rtow_multi_render_rgb8.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.POINTER(Stats)]
+        L.rtow_render_device_rgb8.argtypes = [C.c_void_p, C.POINTER(Config), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.rtow_render_rgb8.argtypes = [C.c_void_p, C.POINTER(Scene), C.POINTER(Config), C.c_void_p, C.POINTER(Stats)]
+    L.rtow_profile_collect.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     if hasattr(L, "rtow_debug_schedule"):  # (absent from older builds loaded through RTOW_LIB for A/B runs)
         L.rtow_debug_schedule.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(C.c_uint32), C.c_int32]
     ver = L.rtow_abi_version()
@@ -344,6 +350,33 @@ class Context:
                                 C.byref(st)), "rtow_render")
         return out, st
 
+    def render_rgb8(self, scene, cfg: Config, want_stats=True):
+        """Upload + render + write_color on the device + D2H of the bytes: (numpy [rows, W, 3] uint8, Stats | None)."""
+        import numpy as np
+
+        s = scene.c if isinstance(scene, HostScene) else scene
+        rows = lib().rtow_local_rows(C.byref(cfg))
+        if rows < 0:
+            check(rows, "rtow_local_rows")
+        out = np.zeros((rows, cfg.image_width, 3), dtype=np.uint8)
+        st = Stats() if want_stats else None
+        check(lib().rtow_render_rgb8(self._h, C.byref(s), C.byref(cfg), out.ctypes.data_as(C.c_void_p),
+                                     C.byref(st) if st is not None else None), "rtow_render_rgb8")
+        return out, st
+
+    def render_device_rgb8(self, cfg: Config, d_ptr: int, stream: int = 0, want_stats=False):
+        """This rank's rows as bytes on the device (write_color fused into the reduce kernel)."""
+        st = Stats() if want_stats else None
+        check(lib().rtow_render_device_rgb8(self._h, C.byref(cfg), C.c_void_p(d_ptr), C.c_void_p(stream),
+                                            C.byref(st) if st is not None else None), "rtow_render_device_rgb8")
+        return st
+
+    def profile_collect(self):
+        """(trace-kernel ms since the last collect, launches); raises if a launch dropped samples."""
+        ms, n = C.c_double(), C.c_int32()
+        check(lib().rtow_profile_collect(self._h, C.byref(ms), C.byref(n)), "rtow_profile_collect")
+        return ms.value, n.value
+
     def close(self):
         if self._h:
             lib().rtow_ctx_destroy(self._h)
@@ -395,6 +428,17 @@ class MultiContext:
         st = Stats() if want_stats else None
         check(lib().rtow_multi_render(self._h, C.byref(cfg), out.ctypes.data_as(_pd),
                                       C.byref(st) if st is not None else None), "rtow_multi_render")
+        return out, st
+
+    def render_rgb8(self, cfg: Config, want_stats=True):
+        """The frame as the PPM's bytes: write_color by the owning rank, bytes gathered, rows placed on the first
+        device, one copy.  ([H, W, 3] uint8, Stats | None)"""
+        import numpy as np
+
+        out = np.zeros((cfg.image_height, cfg.image_width, 3), dtype=np.uint8)
+        st = Stats() if want_stats else None
+        check(lib().rtow_multi_render_rgb8(self._h, C.byref(cfg), out.ctypes.data_as(C.c_void_p),
+                                           C.byref(st) if st is not None else None), "rtow_multi_render_rgb8")
         return out, st
 
     def close(self):

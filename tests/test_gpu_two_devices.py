@@ -60,6 +60,56 @@ def test_persistent_handle_on_one_device_many_frames(ctx):
         rtow.MultiContext([0, 0], use_rccl=True)  # RCCL refuses one device twice: an error, not a wrong image
 
 
+@pytest.mark.parametrize("devices,use_rccl", [([0], True), ([0, 0, 0], False)])
+def test_multi_handle_rgb8_bytes_equal_the_one_device_bytes(ctx, devices, use_rccl):
+    """rtow_multi_render_rgb8 (write_color by the rank that owns the pixel, bytes gathered, rows placed by a kernel
+    on the first device, one copy into the caller's buffer) against rtow_render_rgb8 of one context: the same bytes,
+    for a one-rank RCCL communicator and for three ranks without the collective; strip heights that tile evenly,
+    unevenly (ranks with fewer rows: zero-padded strip buffers) and rows whose byte count is not a multiple of 16."""
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    m = rtow.MultiContext(devices, use_rccl=use_rccl)
+    try:
+        m.upload(scene)
+        for (w, h, spp, ns, tr, prec) in ((150, 100, 12, 3, 8, rtow.F64_STRICT), (96, 64, 8, 2, 4, rtow.F64_FAST),
+                                          (150, 100, 20, 1, 16, rtow.F64_FAST), (67, 45, 6, 2, 2, rtow.F64_STRICT)):
+            cfg = rtow.make_config(w, h, spp, ns, 30, seed=7, precision=prec, tile_rows=tr)
+            one8, st = ctx.render_rgb8(scene, cfg)
+            got8, s = m.render_rgb8(cfg)
+            assert got8.shape == one8.shape and np.array_equal(got8, one8), int((got8 != one8).sum())
+            assert s.samples == st.samples and s.segments == st.segments
+            again, none = m.render_rgb8(cfg, want_stats=False)
+            assert none is None and np.array_equal(again, one8)
+            sums, _ = m.render(cfg)  # the f64 form goes through the same placement kernel
+            assert np.array_equal(sums, ctx.render(scene, cfg)[0])
+    finally:
+        m.close()
+
+
+def test_failed_gather_enqueue_is_an_error_code_and_the_handle_refuses_further_frames(ctx, monkeypatch):
+    """A rank whose side of the gather cannot be enqueued (forced with RTOW_MULTI_FAIL_GATHER, read at create):
+    every communicator is aborted before anything is waited for, the call returns RTOW_EHIP, later frames on the
+    handle are refused — never a hang."""
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    monkeypatch.setenv("RTOW_MULTI_FAIL_GATHER", "0")
+    m = rtow.MultiContext([0], use_rccl=True)
+    monkeypatch.delenv("RTOW_MULTI_FAIL_GATHER")
+    try:
+        m.upload(scene)
+        cfg = rtow.make_config(96, 64, 8, 2, 30, seed=7, precision=rtow.F64_FAST)
+        with pytest.raises(rtow.RtowError, match="ncclGather"):
+            m.render(cfg)
+        with pytest.raises(rtow.RtowError, match="aborted"):
+            m.render_rgb8(cfg)
+    finally:
+        m.close()
+    ok = rtow.MultiContext([0], use_rccl=True)  # a new handle works
+    try:
+        ok.upload(scene)
+        assert np.array_equal(ok.render(cfg)[0], ctx.render(scene, cfg)[0])
+    finally:
+        ok.close()
+
+
 @needs_two
 def test_rccl_gather_over_two_devices_single_process(ctx):
     scene = rtow.HostScene.cover(11, 1.5, False)
@@ -74,6 +124,9 @@ def test_rccl_gather_over_two_devices_single_process(ctx):
                 img, s = m.render(cfg)
                 assert np.array_equal(img, whole), int((img != whole).sum())
                 assert s.segments == st.segments
+            one8, _ = ctx.render_rgb8(scene, cfg)
+            got8, _ = m.render_rgb8(cfg)  # bytes over RCCL (ncclUint8), placed on device 0
+            assert np.array_equal(got8, one8), int((got8 != one8).sum())
     finally:
         m.close()
     one_shot, _ = rtow.render_multi([0, 1], scene, rtow.make_config(150, 100, 12, 3, 30, seed=9, precision=rtow.F64_STRICT))
@@ -103,3 +156,6 @@ def test_rtweekend_two_gpus_prints_the_one_gpu_image():
     plain = subprocess.run(base, capture_output=True, check=True)
     two = subprocess.run(base + ["--gpus", "2"], capture_output=True, check=True)
     assert two.stdout == plain.stdout
+    p6 = subprocess.run(base + ["--p6"], capture_output=True, check=True)
+    two6 = subprocess.run(base + ["--gpus", "2", "--p6"], capture_output=True, check=True)
+    assert two6.stdout == p6.stdout and two6.stdout.startswith(b"P6")

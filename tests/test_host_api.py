@@ -203,32 +203,48 @@ def _schedule(cfg):
     return [(pairs[2 * i], pairs[2 * i + 1]) for i in range(n)]
 
 
-@pytest.mark.parametrize("spp,ns", [(100, 10), (100, 4), (500, 4), (99, 3), (7, 3), (1, 1), (16, 1), (1024, 64), (97, 1)])
+def _expected_levels(s0, total, chunk=10):
+    """level_plan of csrc/rtow_capi.cpp restated: the divisor of gcd(first sample, sample count) nearest `chunk` in
+    log distance (ties: the smaller) when it lies within a factor of two of it; otherwise levels of exactly `chunk`
+    samples with the remainder added to the last one (a range shorter than a chunk: one level)."""
+    import math
+    g = math.gcd(total, s0)
+    best = min((e for e in range(1, g + 1) if g % e == 0), key=lambda e: (round(abs(math.log(e / chunk)), 12), e))
+    if chunk <= 2 * best <= 4 * chunk:
+        return [(s0 + k * best, best) for k in range(total // best)]
+    n = max(total // chunk, 1)
+    d = chunk if n > 1 else total
+    return [(s0 + k * d, d) for k in range(n - 1)] + [(s0 + (n - 1) * d, total - (n - 1) * d)]
+
+
+@pytest.mark.parametrize("spp,ns", [(100, 10), (100, 4), (500, 4), (99, 3), (7, 3), (1, 1), (16, 1), (1024, 64), (97, 1),
+                                    (101, 1), (127, 1), (131, 1), (202, 2), (23, 1), (1009, 1)])
 def test_fast_build_schedule_properties(spp, ns, monkeypatch):
-    """The levels a fast-build render is cut into (pure host arithmetic): equal runs that tile the effective
-    sample range, of the divisor of the range nearest RTOW_SCHED_CHUNK (10) — whatever nstreams is; the strict
-    build keeps one level per stream, the reference's decomposition (src/render.cpp:169-185)."""
+    """The levels a fast-build render is cut into (pure host arithmetic): runs that tile the effective sample range
+    — the divisor of the range nearest RTOW_SCHED_CHUNK (10) when there is one within a factor of two, else runs of
+    10 with the remainder on the last — whatever nstreams is; the strict build keeps one level per stream, the
+    reference's decomposition (src/render.cpp:169-185).  Never `spp` levels of one sample (101, 127, 131: primes)."""
     monkeypatch.delenv("RTOW_SCHED_CHUNK", raising=False)
     eff = spp // ns * ns
     s = _schedule(rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST))
     assert s[0][0] == 0 and sum(c for _, c in s) == eff
     assert all(a + c == b for (a, c), (b, _) in zip(s, s[1:]))
+    assert s == _expected_levels(0, eff)
     d = s[0][1]
-    assert all(c == d for _, c in s) and eff % d == 0
-    import math
-    best = min((e for e in range(1, eff + 1) if eff % e == 0), key=lambda e: (abs(math.log(e / 10)), e))
-    assert d == best
+    assert all(c == d for _, c in s[:-1]) and d <= s[-1][1] < 2 * max(d, 10)
+    if eff >= 10:  # bounded work items and partial images: nothing shorter than half a chunk, nothing longer than two
+        assert all(5 <= c <= 20 for _, c in s), s
     # the same effective spp through another stream count: the same levels
     assert _schedule(rtow.make_config(64, 48, eff, 1, 10, precision=rtow.F64_FAST)) == s
     # strict build: one level per stream
     strict = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_STRICT)
     assert _schedule(strict) == [(k * (spp // ns), spp // ns) for k in range(ns)]
-    # a stream range covers its own samples, in levels that divide its first sample index too
+    # a stream range covers its own samples
     if ns >= 2:
         part = rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST, stream_first=1, stream_count=ns - 1)
         ps = _schedule(part)
         assert ps[0][0] == spp // ns and sum(c for _, c in ps) == (ns - 1) * (spp // ns)
-        assert all(c == ps[0][1] for _, c in ps) and ps[0][0] % ps[0][1] == 0
+        assert ps == _expected_levels(spp // ns, (ns - 1) * (spp // ns))
     monkeypatch.setenv("RTOW_SCHED_CHUNK", "0")  # off: the strict build's levels
     assert _schedule(rtow.make_config(64, 48, spp, ns, 10, precision=rtow.F64_FAST)) == _schedule(strict)
 
