@@ -13,6 +13,8 @@
 // before the trace kernel may use the image (same rules as validate_scene_image()).
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <hip/hip_fp16.h>
 #include <math.h>
 #include <stdint.h>
 
@@ -39,6 +41,14 @@ struct Scratch {
   uint32_t *glob = nullptr;            // [8]: 0..2 centroid min, 3..5 centroid max (ordered u32), 6 scale bits, 7 error flag
   void *sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
+  // 4-wide collapse (triangle meshes): per 4-wide node, breadth-first
+  int32_t *b4_src = nullptr;    // [capacity] radix-tree node each 4-wide node expands
+  int32_t *b4_child = nullptr;  // [capacity][4] the children as radix-tree refs (kB4Empty = none)
+  uint32_t *b4_cw = nullptr;    // [capacity][4] child words of the image (rtow_bvh4.h: ref21)
+  uint32_t *b4_cnt = nullptr, *b4_pos = nullptr;  // [capacity] inner children per node of a level, their exclusive scan
+  void *scan_tmp = nullptr;
+  size_t scan_tmp_bytes = 0;
+  int b4_nodes = 0, b4_depth = 0;
 };
 
 __device__ __forceinline__ uint32_t ordered(float f) {
@@ -309,11 +319,172 @@ __global__ void k_validate(const unsigned char *blob, uint32_t n_nodes, uint32_t
   if (!ok) atomicOr(err, 1u);
 }
 
+// ---- 4-wide image for the BVH4 kernel (rtow_bvh4.h), collapsed from the radix tree on the device ----------------
+// The host builder collapses its SAH tree; this is the same greedy collapse over the LBVH: a 4-wide node starts from
+// the two children of a radix-tree node and, while it has fewer than four, replaces the inner child of largest
+// surface area by that child's two children.  "Inner" = covers more than leaf_max triangles; anything smaller is a
+// leaf of the 4-wide tree, and because a radix-tree node covers a contiguous range of the SORTED triangles, the
+// triangle records are simply laid out in sorted order: a leaf is (first, count) of its range — no allocation.
+// One level of the tree per launch pair (breadth-first order, which the kernel's LDS staging of the top of the tree
+// needs): k_b4_expand picks every node's children and counts the inner ones, an exclusive scan turns the counts
+// into the positions of the next level, k_b4_link writes the child words and the next level's work list.
+constexpr int32_t kB4Empty = 0x7fffffff;
+constexpr uint32_t kB4RefNone = 0x1fffffu, kB4RefLeaf = 1u << 20;  // = kRefNone, kRefLeaf of rtow_bvh4.h
+constexpr uint32_t kB4MaxNodes = 1u << 20, kB4MaxTris = (1u << 18) - 4u;
+
+struct B4Tree {
+  const int32_t *child_l, *child_r, *first, *last;
+  const float *ibox, *pbox;
+  const uint32_t *vals;
+  int leaf_max;
+  __device__ int count(int32_t ref) const { return ref < 0 ? 1 : last[ref] - first[ref] + 1; }
+  __device__ bool inner(int32_t ref) const { return ref >= 0 && ref != kB4Empty && count(ref) > leaf_max; }
+  __device__ const float *box(int32_t ref) const {
+    return ref < 0 ? pbox + (size_t)vals[ref & 0x7fffffff] * 6 : ibox + (size_t)ref * 6;
+  }
+  __device__ float area(int32_t ref) const {
+    const float *b = box(ref);
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+__global__ void k_b4_expand(B4Tree t, int level_n, int base, int root_is_leaf, int32_t root_ref, const int32_t *src,
+                            int32_t *child, uint32_t *cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= level_n) return;
+  int32_t ch[4] = {kB4Empty, kB4Empty, kB4Empty, kB4Empty};
+  int nc = 0;
+  if (root_is_leaf) {  // a mesh of at most leaf_max triangles: one node, one leaf
+    ch[nc++] = root_ref;
+  } else {
+    const int32_t me = src[base + i];
+    ch[nc++] = t.child_l[me];
+    ch[nc++] = t.child_r[me];
+    while (nc < 4) {
+      int pick = -1;
+      float best = -1.0f;
+      for (int c = 0; c < nc; ++c)
+        if (t.inner(ch[c])) {
+          const float a = t.area(ch[c]);
+          if (a > best) {
+            best = a;
+            pick = c;
+          }
+        }
+      if (pick < 0) break;
+      const int32_t x = ch[pick];
+      ch[pick] = t.child_l[x];
+      ch[nc++] = t.child_r[x];
+    }
+  }
+  uint32_t inner = 0;
+  for (int c = 0; c < 4; ++c) {
+    child[(size_t)(base + i) * 4 + c] = ch[c];
+    inner += t.inner(ch[c]) ? 1u : 0u;
+  }
+  cnt[i] = inner;
+}
+
+__global__ void k_b4_link(B4Tree t, int level_n, int base, int next_base, const int32_t *child, const uint32_t *pos,
+                          int32_t *src, uint32_t *cw, uint32_t *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= level_n) return;
+  uint32_t k = 0;
+  for (int c = 0; c < 4; ++c) {
+    const int32_t ref = child[(size_t)(base + i) * 4 + c];
+    uint32_t w;
+    if (ref == kB4Empty) {
+      w = kB4RefNone;
+    } else if (t.inner(ref)) {
+      const uint32_t slot = (uint32_t)next_base + pos[i] + k++;
+      if (slot >= kB4MaxNodes) atomicOr(err, 2u);
+      src[slot < kB4MaxNodes ? slot : 0u] = ref;
+      w = slot;
+    } else {
+      const uint32_t f = ref < 0 ? (uint32_t)(ref & 0x7fffffff) : (uint32_t)t.first[ref];
+      const uint32_t n = (uint32_t)t.count(ref);
+      if (n < 1u || n > 4u || f + n > kB4MaxTris) atomicOr(err, 4u);
+      w = kB4RefLeaf | (f << 2) | ((n - 1u) & 3u);
+    }
+    cw[(size_t)(base + i) * 4 + c] = w;
+  }
+}
+
+// planes of one node in the image's format: binary32 (128-byte node) or binary16 in the mesh's frame (64-byte node)
+__global__ void k_b4_nodes(B4Tree t, int n4, const int32_t *child, const uint32_t *cw, unsigned char *blob, int half,
+                           double c0, double c1, double c2, double s0, double s1, double s2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const uint32_t node_bytes = half ? 64u : 128u, child_off = half ? 48u : 96u;
+  float *f = reinterpret_cast<float *>(blob + (size_t)i * node_bytes);
+  __half *h = reinterpret_cast<__half *>(blob + (size_t)i * node_bytes);
+  uint32_t *w = reinterpret_cast<uint32_t *>(blob + (size_t)i * node_bytes + child_off);
+  const double mc[3] = {c0, c1, c2}, ms[3] = {s0, s1, s2};
+  for (int c = 0; c < 4; ++c) {
+    const int32_t ref = child[(size_t)i * 4 + c];
+    for (int k = 0; k < 3; ++k) {
+      float lo = INFINITY, hi = -INFINITY;  // empty slot: inverted box, never hit
+      if (ref != kB4Empty) {
+        const float *b = t.box(ref);  // padded binary32 planes, conservative for the f32 slab test (k_morton, k_refit)
+        lo = b[k];
+        hi = b[3 + k];
+      }
+      if (half) {
+        // outwards in both steps: binary64 -> binary32 and binary32 -> binary16 with the same directed rounding
+        h[k * 8 + c] = __float2half_rd(__double2float_rd(((double)lo - mc[k]) * ms[k]));
+        h[k * 8 + 4 + c] = __float2half_ru(__double2float_ru(((double)hi - mc[k]) * ms[k]));
+      } else {
+        f[k * 8 + c] = lo;
+        f[k * 8 + 4 + c] = hi;
+      }
+    }
+    w[c] = cw[(size_t)i * 4 + c];
+  }
+  if (!half) {  // the 16 unused bytes of a 128-byte node
+    uint32_t *pad = reinterpret_cast<uint32_t *>(blob + (size_t)i * node_bytes + 112u);
+    pad[0] = pad[1] = pad[2] = pad[3] = 0u;
+  }
+}
+
+// triangle records and their material indices in SORTED order (= leaf order)
+__global__ void k_b4_records(int nt, const uint32_t *vals, const double *tri, const int32_t *prim_mat,
+                             unsigned char *blob, uint32_t off_tri, uint32_t off_pmat) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nt) return;
+  const uint32_t p = vals[j];
+  const double2 *srcp = reinterpret_cast<const double2 *>(tri + (size_t)p * 12);
+  double2 *dst = reinterpret_cast<double2 *>(blob + off_tri + (size_t)j * 96);
+  for (int k = 0; k < 6; ++k) dst[k] = srcp[k];
+  reinterpret_cast<int32_t *>(blob + off_pmat)[j] = prim_mat[p];
+}
+
+// what the walk's termination and addressing rest on (validate_bvh4_image of rtow_bvh4.h): child links point to
+// LATER nodes, leaves stay inside the record section
+__global__ void k_b4_validate(const unsigned char *blob, int n4, int half, int nt, uint32_t *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(blob + (size_t)i * (half ? 64u : 128u) + (half ? 48u : 96u));
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t r = w[c];
+    if (r == kB4RefNone) continue;
+    bool ok = (r & ~0x1fffffu) == 0u;
+    if (ok && (r & kB4RefLeaf)) {
+      const uint32_t f = (r & (kB4RefLeaf - 1u)) >> 2, n = (r & 3u) + 1u;
+      ok = f + n <= (uint32_t)nt;
+    } else if (ok) {
+      ok = (int)r > i && (int)r < n4;
+    }
+    if (!ok) atomicOr(err, 8u);
+  }
+}
+
 void release(Scratch *s) {
   if (!s) return;
   void *ptrs[] = {s->pbox,     s->pbox64,  s->keys_a,     s->keys_b,      s->vals_a, s->vals_b, s->child_l,
                   s->child_r,  s->first,   s->last,       s->parent_int,  s->parent_leaf,
-                  s->ibox,     s->size,    s->flags,      s->glob,        s->sort_tmp};
+                  s->ibox,     s->size,    s->flags,      s->glob,        s->sort_tmp,
+                  s->b4_src,   s->b4_child, s->b4_cw,     s->b4_cnt,      s->b4_pos, s->scan_tmp};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -403,6 +574,89 @@ int lbvh_emit(void *handle, int leaf_max, unsigned char *blob_dev, uint32_t off_
                      s->flags, blob_dev, off_ids, (uint32_t)n_nodes);
   hipLaunchKernelGGL(k_validate, dim3((n_nodes + 1 + B - 1) / B), dim3(B), 0, st, blob_dev, (uint32_t)n_nodes,
                      off_ids, n, s->glob + 7);
+  uint32_t err = 1;
+  const bool good = hipMemcpyAsync(&err, s->glob + 7, sizeof err, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                    hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+  if (!good) return 3;
+  return err ? 4 : 0;
+}
+
+// 4-wide collapse of the tree lbvh_build left in scratch memory (triangle meshes; leaf_max <= 4).  Level by level:
+// two launches, one scan and one 8-byte read-back per level of the 4-wide tree.  Returns the number of nodes, the
+// depth (levels of nodes, root = 1) and the root's padded box (the frame of the binary16 format).
+int lbvh_bvh4_collapse(void *handle, int leaf_max, void *stream, int *n_nodes, int *depth, float root_box[6]) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Scratch *s = static_cast<Scratch *>(handle);
+  if (!s || leaf_max < 1 || leaf_max > 4) return 1;
+  const int n = s->n;
+  if ((uint32_t)n > kB4MaxTris) return 5;  // (the caller falls back to the binary walk)
+  const size_t cap = (size_t)s->capacity;
+  if (!s->b4_src) {
+    size_t tb = 0;
+    bool ok = dev_alloc(s->b4_src, cap) && dev_alloc(s->b4_child, cap * 4) && dev_alloc(s->b4_cw, cap * 4) &&
+              dev_alloc(s->b4_cnt, cap) && dev_alloc(s->b4_pos, cap) &&
+              rocprim::exclusive_scan(nullptr, tb, s->b4_cnt, s->b4_pos, 0u, cap, rocprim::plus<uint32_t>(), st) == hipSuccess &&
+              hipMalloc(&s->scan_tmp, tb ? tb : 16) == hipSuccess;
+    if (!ok) return 2;
+    s->scan_tmp_bytes = tb;
+  }
+  B4Tree t{s->child_l, s->child_r, s->first, s->last, s->ibox, s->pbox, s->vals_b, leaf_max};
+  const bool root_is_leaf = n <= leaf_max;
+  const int32_t root_ref = n == 1 ? (int32_t)(0u | 0x80000000u) : 0;
+  const int32_t zero = 0;
+  bool good = hipMemcpyAsync(s->b4_src, &zero, sizeof zero, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemsetAsync(s->glob + 7, 0, sizeof(uint32_t), st) == hipSuccess;
+  int base = 0, level_n = 1, levels = 0;
+  const int B = 256;
+  while (good && level_n > 0) {
+    ++levels;
+    const int G = (level_n + B - 1) / B;
+    if ((size_t)base + (size_t)level_n > cap) return 5;
+    hipLaunchKernelGGL(k_b4_expand, dim3(G), dim3(B), 0, st, t, level_n, base, root_is_leaf ? 1 : 0, root_ref, s->b4_src,
+                       s->b4_child, s->b4_cnt);
+    size_t tb = s->scan_tmp_bytes;
+    good = rocprim::exclusive_scan(s->scan_tmp, tb, s->b4_cnt, s->b4_pos, 0u, (size_t)level_n, rocprim::plus<uint32_t>(), st) == hipSuccess;
+    if (!good) break;
+    const int next_base = base + level_n;
+    hipLaunchKernelGGL(k_b4_link, dim3(G), dim3(B), 0, st, t, level_n, base, next_base, s->b4_child, s->b4_pos, s->b4_src,
+                       s->b4_cw, s->glob + 7);
+    uint32_t tail[2] = {0u, 0u};  // inner children of the level = its last position + its last count
+    good = hipMemcpyAsync(&tail[0], s->b4_pos + (level_n - 1), 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+           hipMemcpyAsync(&tail[1], s->b4_cnt + (level_n - 1), 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+           hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+    base = next_base;
+    level_n = (int)(tail[0] + tail[1]);
+    if ((uint32_t)base + (uint32_t)level_n > kB4MaxNodes) return 5;
+  }
+  uint32_t err = 1;
+  float rb[6] = {0, 0, 0, 0, 0, 0};
+  good = good && hipMemcpyAsync(&err, s->glob + 7, sizeof err, hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipMemcpyAsync(rb, n > 1 ? s->ibox : s->pbox, sizeof rb, hipMemcpyDeviceToHost, st) == hipSuccess &&
+         hipStreamSynchronize(st) == hipSuccess;
+  if (!good) return 3;
+  if (err) return (err & 6u) ? 5 : 4;
+  s->b4_nodes = base;
+  s->b4_depth = levels;
+  *n_nodes = base;
+  *depth = levels;
+  for (int k = 0; k < 6; ++k) root_box[k] = rb[k];
+  return 0;
+}
+
+// Writes the 4-wide image: nodes (binary32 planes, or binary16 planes in the frame map_c / map_s), triangle records
+// and material indices in sorted order.  The caller copies the material records to off_mats.  Validates the links.
+int lbvh_bvh4_emit(void *handle, unsigned char *blob_dev, int half, const double map_c[3], const double map_s[3],
+                   uint32_t off_tri, uint32_t off_pmat, const double *tri, const int32_t *prim_mat, void *stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Scratch *s = static_cast<Scratch *>(handle);
+  if (!s || s->b4_nodes <= 0) return 1;
+  const int n = s->n, n4 = s->b4_nodes, B = 256;
+  B4Tree t{s->child_l, s->child_r, s->first, s->last, s->ibox, s->pbox, s->vals_b, 0};
+  hipLaunchKernelGGL(k_b4_nodes, dim3((n4 + B - 1) / B), dim3(B), 0, st, t, n4, s->b4_child, s->b4_cw, blob_dev, half,
+                     map_c[0], map_c[1], map_c[2], map_s[0], map_s[1], map_s[2]);
+  hipLaunchKernelGGL(k_b4_records, dim3((n + B - 1) / B), dim3(B), 0, st, n, s->vals_b, tri, prim_mat, blob_dev, off_tri,
+                     off_pmat);
+  hipLaunchKernelGGL(k_b4_validate, dim3((n4 + B - 1) / B), dim3(B), 0, st, blob_dev, n4, half, n, s->glob + 7);
   uint32_t err = 1;
   const bool good = hipMemcpyAsync(&err, s->glob + 7, sizeof err, hipMemcpyDeviceToHost, st) == hipSuccess &&
                     hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;

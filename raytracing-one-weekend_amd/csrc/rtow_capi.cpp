@@ -1252,6 +1252,8 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
     P.tail_bound = c->knobs.tail_bound > 0 ? (uint32_t)c->knobs.tail_bound : (uint32_t)std::min<unsigned long long>(b, 0xfffffff0ull);
   }
   P.dropped = (unsigned long long *)c->dropped.p;
+  P.inv_wm1 = 1.0 / (double)(cfg->image_width - 1);  // (W = 1: inf, and the fast build's u = 0 * inf is NaN like the
+  P.inv_hm1 = 1.0 / (double)(cfg->image_height - 1);  //  strict build's 0 / 0 — the reference divides by zero there too)
   P.max_child_rays = cfg->max_child_rays;
   P.rank = cfg->rank;
   P.nranks = cfg->nranks;

@@ -102,6 +102,7 @@ struct TraceParams {
   int32_t spt_last;        // samples of the launch's LAST level (= spt unless the host's schedule ends on a longer one:
                            // a sample count with no divisor near the aimed-at item length, rtow_capi.cpp level_plan)
   uint32_t tail_bound;     // trips a wave may spend in the end-of-launch protocol before it gives up (structural bound)
+  double inv_wm1, inv_hm1; // 1 / (W - 1), 1 / (H - 1): the fast builds multiply where the reference divides (src/render.cpp:158-159)
   int32_t max_child_rays;
   int32_t rank, nranks, tile_rows;
   int32_t local_rows;

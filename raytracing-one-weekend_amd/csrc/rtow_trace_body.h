@@ -366,7 +366,11 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
   uint32_t partners = 0u;  // owner: stack of its helpers' lane ids (6 bits each, most recent lowest);
                            // helper: its owner's lane id
   int n_out = 0;           // owner: donated samples not yet added
-  uint32_t tail_trips = 0u;
+  // end-of-launch protocol: trips this wave may still spend in it (structural bound, computed by the host).  A
+  // count-down held in a register from the start: read at its point of use — a scalar load from the kernel-argument
+  // segment and an lgkmcnt wait in EVERY trip of a draining wave — it cost +0.2 ms on the end of every launch.
+  uint32_t tail_left = P.tail_bound;
+  asm volatile("" : "+v"(tail_left));
   ItemPool pool;  // wave-uniform: this wave's batch of work items
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
 #ifdef RTOW_TAILSTAT  // (experiment build: what a wave still holds when it first finds the queue empty, and how long that takes)
@@ -559,12 +563,10 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       // structural bound on the tail (every wait above ends when a bounded path ends; this makes
       // the exit independent of that argument): give up donating, never hang
       // (x64: a stopped-and-resumed walk spreads one segment over several trips)
-      // (the bound — 64 x (4096 + 8 (max_child_rays + 2)(longest item + 1)) trips — is computed by the host and read
-      // from the kernel-argument segment here, where it is needed: once per trip of a draining wave)
-      const RTOW_CONST TraceParams *kpt = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(kpt));  // (opaque per trip, like kp above: the load must not be hoisted into an SGPR held across the loop)
-      if (++tail_trips > kpt->tail_bound) {
+      // (the bound — 64 x (4096 + 8 (max_child_rays + 2)(longest item + 1)) trips — comes from the host)
+      if (tail_left == 0u) {
         if (!done || holding) {  // samples dropped: the host turns this into an error (the word is sticky across launches)
+          const RTOW_CONST TraceParams *kpt = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
           atomicAdd(&P.counters[47], 1ull);
           atomicAdd(kpt->dropped, 1ull);
         }
@@ -572,6 +574,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         helping = false;
         holding = false;
         n_out = 0;
+      } else {
+        --tail_left;
       }
     }
     if (__ballot(!done || holding) == 0ull) break;
@@ -591,18 +595,22 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     // (counter = (request, sample, pixel)), so nothing changes in the image.
     const bool do_regen = live && need_sample;
     const bool do_scat = live && pending_hit;
-    V3 where = {0, 0, 0}, normal = {0, 0, 0};
+    // (read only by the lanes of `do_scat`, here and in the two scatter blocks below: for every other lane the value
+    // is unspecified — `anyv` — which spares the dozen v_mov a zero initialiser costs in every trip)
+    V3 normal = anyv3();
     bool front = true;
     int mi = 0, kind = 0;
-    real m_fuzz = 0, m_ir = 0;
+    real m_fuzz = anyv(real(0)), m_ir = anyv(real(0));
 #ifdef RTOW_FAST_MATH
-    V3 m_att = {1, 1, 1};
+    V3 m_att = anyv3();
 #endif
     if (do_scat) {
       // rebuild the Hit of the winner (src/common-model.cpp:83-90, :121).  The walking
       // kernels read the winner's record, its material index and the material from the
       // LDS scene image (a chain of three dependent loads: LDS latency, not L2's)
-      where = ro + rd * best.t;
+      // (the hit point replaces the ray origin IN PLACE: it is the origin of the scattered ray, and a separate
+      // `where` copied into `ro` at the end of the stage cost the compiler a dozen v_mov_b64 per trip around the merge)
+      ro = ro + rd * best.t;
       const int pid = best.prim;
       if constexpr (KERNEL == 4) {
         // triangles only: the un-normalised normal e1 x e2 of the record (src/common-model.cpp:121)
@@ -642,7 +650,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
 #endif
             inward = p3.x < 0.0;
           }
-          normal = normalize(where - center);
+          normal = normalize(ro - center);
           front = (dot(rd, normal) < real(0.0)) ^ inward;
           normal = front ? normal : -normal;
         } else {
@@ -683,7 +691,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
 #endif
             inward = q[7] < 0.0;
           }
-          normal = normalize(where - center);
+          normal = normalize(ro - center);
           front = (dot(rd, normal) < real(0.0)) ^ inward;
           normal = front ? normal : -normal;
         } else {
@@ -702,7 +710,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
 
     }
     // first block of the sample / of the bounce
-    uint32_t o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u;
+    uint32_t o0 = anyv(0u), o1 = anyv(0u), o2 = anyv(0u), o3 = anyv(0u);
     if (do_regen) g.r = 0u;
     if (do_regen || do_scat) {
       philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
@@ -711,8 +719,9 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     if constexpr (STAMPS) {  // wave-level count of block evaluations: the first active lane reports
       if (__ballot(do_regen || do_scat) != 0ull) stamps.blocks += 1;
     }
-    real ju = 0, jv = 0, jt = 0, px = 0, py = 0;  // new sample: jitter, shutter time, lens-disk candidate
-    V3 rnd = {0, 0, 0}, dirbase = {0, 0, 0};      // bounce: unit-ball candidate, direction before the fuzz term
+    real ju = anyv(real(0)), jv = anyv(real(0)), jt = anyv(real(0)), px = anyv(real(0)), py = anyv(real(0));  // new sample: jitter, shutter time, lens-disk candidate
+    V3 rnd = anyv3(), dirbase = anyv3();          // bounce: unit-ball candidate, direction before the fuzz term
+    BallCand cand = {anyv(0u), anyv(0u), anyv(0u)};  // ... as its 21-bit integers while it may still be rejected
     bool rej = false;
     if (do_regen) {
       // disk sample: y draws first (random-utils.cpp:36).  The first candidate comes with the jitter block.
@@ -725,7 +734,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     if (do_scat) {
       // the first unit-ball candidate of the bounce comes with the dielectric coin (word 2)
       const real coin = (real)o2 * real(0x1p-32);
-      rnd = ball_from_pair(o0, o1);
+      cand = ball_ints(o0, o1);
       if (kind == 2) {
         const real ir = m_ir;
         const V3 unit = normalize(rd);
@@ -745,7 +754,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       } else if (kind == 1) {
         dirbase = reflect(rd, normal);
       }
-      rej = dot(rnd, rnd) >= real(1.0);
+      rej = ball_outside(cand);
     }
     // rejection sampling (random-utils.cpp:23-41): every further block carries two candidates
     uint32_t rej_trips = 0u;  // (diagnostic build only)
@@ -763,11 +772,12 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         }
         rej = px * px + py * py + real(0.0) * real(0.0) >= real(1.0);
       } else {
-        const V3 ca = ball_from_pair(o0, o1), cb = ball_from_pair(o2, o3);
-        rnd = dot(ca, ca) >= real(1.0) ? cb : ca;
-        rej = dot(rnd, rnd) >= real(1.0);
+        const BallCand ca = ball_ints(o0, o1), cb = ball_ints(o2, o3);
+        cand = ball_outside(ca) ? cb : ca;
+        rej = ball_outside(cand);
       }
     }
+    if (do_scat) rnd = ball_point(cand);  // only the accepted candidate becomes a vector
     if constexpr (STAMPS) {  // what the wave ran: as many trips as its unluckiest lane needed
       uint32_t mx = rej_trips, sum = rej_trips;
       for (int off = 32; off >= 1; off >>= 1) {
@@ -781,8 +791,17 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     if (do_regen) {
       // src/render.cpp:158-159, src/common-model.cpp:156-167
       const int from_top_i = P.H - (int)gi - 1;
+#ifdef RTOW_FAST_MATH
+      // the divisors are constants of the launch: their reciprocals come from the host (two scalar loads from the
+      // kernel-argument segment beside the camera block's) instead of two v_rcp_f64 + refinement per new sample
+      const RTOW_CONST TraceParams *kq = (const RTOW_CONST TraceParams *)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(kq));
+      const real u = ((real)(int)j + ju) * (real)kq->inv_wm1;
+      const real v = ((real)from_top_i + jv) * (real)kq->inv_hm1;
+#else
       const real u = fast_div((real)(int)j + ju, (real)(P.W - 1));
       const real v = fast_div((real)from_top_i + jv, (real)(P.H - 1));
+#endif
       // camera block: wave-uniform scalar loads (origin u v horizontal vertical llc | lens t0 t1)
 #ifdef RTOW_REAL_F32
       const RTOW_CONST float *cm = (const RTOW_CONST float *)P.cam32;
@@ -806,13 +825,14 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     if (do_scat) {
       pending_hit = false;
       bool absorbed = false;
-      V3 dir;
+      // (the new direction is written over the old one in both branches; an absorbed path — black, src/render.cpp:120 —
+      // starts a new sample in the next trip and never reads it)
       if (kind == 0) {
         absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
                    rabs(normal.z - rnd.z) < real(1e-8);
-        dir = normal + rnd;
+        rd = normal + rnd;
       } else {
-        dir = dirbase + m_fuzz * rnd;
+        rd = dirbase + m_fuzz * rnd;
       }
       if (absorbed) {
         need_sample = true;  // src/render.cpp:120: black (the lane starts its next sample in the next trip)
@@ -826,8 +846,6 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
 #endif
         ++nb;
         --depth;
-        ro = where;
-        rd = dir;
       }
     }
     const bool tracing = live && !need_sample;  // has a ray to advance in this trip

@@ -138,10 +138,10 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         else
           q1 = cw;
       }
-      // leave through the nearest cell wall
-      const bool sx = tmx <= tmy && tmx <= tmz;
-      const bool sy = !sx && tmy <= tmz;
-      const float tnext = sx ? tmx : (sy ? tmy : tmz);
+      // leave through the nearest cell wall (x before y before z when equal): one v_min3 and two equality tests
+      const float tnext = fminf(fminf(tmx, tmy), tmz);
+      const bool sx = tmx == tnext;
+      const bool sy = !sx && tmy == tnext;
       const int rem = sx ? remx : (sy ? remy : remz);
       walking = rem > 0 && !(tnext > tmax32);
       t_entry = tnext;

@@ -26,8 +26,10 @@ __device__ __forceinline__ T sphere_disc(Vec3<T> o, Vec3<T> d, T a, T cx, T cy, 
 template <class T>
 __device__ __forceinline__ void sphere_resolve(T disc, T h, T a, T inv_a, int id, T tmin, Closest &best) {
   if (disc >= T(0.0)) {
-    T sq = fast_sqrt(disc);
 #if defined(RTOW_FAST_MATH)
+    // (disc == 0 exactly — a tangent ray — gives NaN roots here, which fail both comparisons below: no hit, where the
+    // strict build accepts the double root; the two instructions of a zero guard are not worth that measure-zero case)
+    const T sq = fast_sqrt_pos(disc);
     // both roots at once (one reciprocal per ray): root1 <= root2, so a root1 beyond best.t rules out root2 as
     // well and "the nearer root if it is at or beyond tmin, else the farther one" is the reference's choice
     // (src/common-model.cpp:76-81) with one comparison less
@@ -39,6 +41,7 @@ __device__ __forceinline__ void sphere_resolve(T disc, T h, T a, T inv_a, int id
     }
 #else
     (void)inv_a;
+    const T sq = fast_sqrt(disc);
     T root = (-h - sq) / a;
     bool ok = true;
     if (root < tmin || root > (T)best.t) {

@@ -24,6 +24,17 @@ struct Vec3 {
 };
 typedef Vec3<real> V3;
 typedef Vec3<double> V3d;
+// A valid but unspecified value at no cost: the initialiser of a variable that only SOME lanes assign and only those
+// lanes read.  A zero there is a v_mov per register in every trip of the main loop (the merge of "assigned" and "not
+// assigned" needs a value on both sides); an empty asm statement that claims to define the register gives the merge
+// a value without an instruction.  (__builtin_nondeterministic_value — freeze poison — is folded to zero.)
+template <class T>
+__device__ __forceinline__ T anyv(T) {
+  T x;
+  asm volatile("" : "=v"(x));  // (volatile: one definition per variable — a shared one is COPIED into each)
+  return x;
+}
+__device__ __forceinline__ V3 anyv3() { return V3{anyv(real(0)), anyv(real(0)), anyv(real(0))}; }
 template <class T>
 __device__ __forceinline__ Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 template <class T>
@@ -48,20 +59,41 @@ __device__ __forceinline__ V3d to_f64(Vec3<float> v) { return {(double)v.x, (dou
 __device__ __forceinline__ V3d to_f64(V3d v) { return v; }
 #ifdef RTOW_FAST_MATH
 // fast build: hardware reciprocal / reciprocal-square-root seed (relative error 5e-8 measured,
-// scripts/experiments/seed_accuracy.hip) + ONE third-order step instead of the correctly rounded division and sqrt:
-// rcp  y (1 + e + e^2), e = 1 - x y              3 fma        max relative error 1.1e-16
-// rsq  y (15/8 - 5/4 z + 3/8 z^2), z = x y^2     2 mul 2 fma 1 mul   3.1e-16   (sqrt: x y in place of y, same count)
-// — two Newton steps (4 and 7 operations) measured 1.9e-16 and 2.4e-16; the strict build keeps the IEEE forms.
+// scripts/experiments/seed_accuracy.hip) + ONE refinement step instead of the correctly rounded division and sqrt:
+// rcp   y (1 + e + e^2), e = 1 - x y                    3 fma           max relative error 1.1e-16
+// rsq   y + (y/2) e,     e = 1 - (x y) y                mul fma mul fma (Goldschmidt, second order)  ~4e-15
+// sqrt  s + (s/2)... as h = y/2, s = x y, e = 1/2 - s h, s + s e        mul mul fma fma              ~4e-15
+// Round 4: the square roots dropped from the third-order polynomial y (15/8 - 5/4 z + 3/8 z^2) (3e-16, seven
+// instructions of which two materialise the constant -5/4 in the fmac's destination) to the second-order step:
+// four instructions, inline constants only, no register pair held for 15/8.  The seed's 5e-8 squared is 2.5e-15:
+// twenty ulps of a ray parameter whose consumers (hit / miss decisions at tmin = 1e-3, the shading point) already
+// differ from the strict build by FMA contraction at the same order; the tolerance tests are the judge.  The strict
+// build keeps the IEEE forms.
 __device__ __forceinline__ double fast_rsqrt(double x) {
   const double y = __builtin_amdgcn_rsq(x);
+#ifdef RTOW_SQRT_ORDER3
   const double z = (x * y) * y;
   return y * __builtin_fma(z, __builtin_fma(z, 0.375, -1.25), 1.875);
+#else
+  const double e = __builtin_fma(-(x * y), y, 1.0);
+  return __builtin_fma(y * 0.5, e, y);
+#endif
+}
+// (x > 0 only: x = 0 gives NaN — the callers below either know x > 0 or treat NaN as "no")
+__device__ __forceinline__ double fast_sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+#ifdef RTOW_SQRT_ORDER3
+  const double s = x * y, z = s * y;
+  return s * __builtin_fma(z, __builtin_fma(z, 0.375, -1.25), 1.875);
+#else
+  const double s = x * y, h = y * 0.5;
+  const double e = __builtin_fma(-s, h, 0.5);
+  return __builtin_fma(s, e, s);
+#endif
 }
 __device__ __forceinline__ double fast_sqrt(double x) {
   if (!(x > 0.0)) return 0.0;
-  const double y = __builtin_amdgcn_rsq(x);
-  const double s = x * y, z = s * y;
-  return s * __builtin_fma(z, __builtin_fma(z, 0.375, -1.25), 1.875);
+  return fast_sqrt_pos(x);
 }
 __device__ __forceinline__ double fast_rcp(double x) {
   const double y = __builtin_amdgcn_rcp(x);
@@ -72,6 +104,7 @@ __device__ __forceinline__ double fast_div(double n, double d) { return n * fast
 #else
 __device__ __forceinline__ double fast_div(double n, double d) { return n / d; }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double fast_sqrt_pos(double x) { return sqrt(x); }
 __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
 #endif
@@ -81,6 +114,7 @@ __device__ __forceinline__ float fast_rsqrt(float x) {
   return y * (1.5f - 0.5f * x * y * y);
 }
 __device__ __forceinline__ float fast_sqrt(float x) { return x > 0.0f ? __builtin_amdgcn_sqrtf(x) : 0.0f; }
+__device__ __forceinline__ float fast_sqrt_pos(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rcp(float x) {
   float y = __builtin_amdgcn_rcpf(x);
   return y * (2.0f - x * y);

@@ -70,10 +70,28 @@ __device__ __forceinline__ void rng_disk2(Rng &g, uint32_t k0, uint32_t k1, real
 // Unit-ball candidates: 21 bits per coordinate, one candidate per pair of words (x, y: the top 21
 // bits of the two words; z: the 11 + 10 low bits left over).  The first block of a bounce carries
 // one candidate (words 0, 1) and the dielectric coin (word 2, 32 bits); a further block carries two.
-__device__ __forceinline__ V3 ball_from_pair(uint32_t lo, uint32_t hi) {
-  const real s21 = real(0x1p-21);
-  return V3{(real)(lo >> 11) * s21, (real)(hi >> 11) * s21, (real)((lo & 0x7ffu) | ((hi & 0x3ffu) << 11)) * s21};
+// The candidate as its three 21-bit integers (X, Y, Z) = 2^21 (x, y, z).  The rejection test of random_in_unit_sphere
+// (src/random-utils.cpp:23-29: length2 >= 1) runs on them: x*x + y*y + z*z >= 1 <=> X*X + Y*Y + Z*Z >= 2^42, and the
+// binary64 form is EXACT for these operands (each square has 42 significant bits, the sums stay below 2^44 multiples
+// of 2^-42), so the integer test takes the same decision as the reference expression bit for bit — in three
+// v_mad_u64_u32 and a compare instead of three conversions, three scalings, three multiply-adds and a compare.
+// Only the ACCEPTED candidate is converted to floating point (round 4: -6 binary64-rate instructions per candidate
+// inside the rejection loop).
+struct BallCand {
+  uint32_t x, y, z;
+};
+__device__ __forceinline__ BallCand ball_ints(uint32_t lo, uint32_t hi) {
+  return BallCand{lo >> 11, hi >> 11, (lo & 0x7ffu) | ((hi & 0x3ffu) << 11)};
 }
+__device__ __forceinline__ bool ball_outside(BallCand c) {
+  const unsigned long long n2 = (unsigned long long)c.x * c.x + (unsigned long long)c.y * c.y + (unsigned long long)c.z * c.z;
+  return (uint32_t)(n2 >> 32) >= (1u << 10);  // n2 >= 2^42
+}
+__device__ __forceinline__ V3 ball_point(BallCand c) {
+  const real s21 = real(0x1p-21);
+  return V3{(real)c.x * s21, (real)c.y * s21, (real)c.z * s21};
+}
+__device__ __forceinline__ V3 ball_from_pair(uint32_t lo, uint32_t hi) { return ball_point(ball_ints(lo, hi)); }
 __device__ __forceinline__ V3 rng_scatter(Rng &g, uint32_t k0, uint32_t k1, real &coin) {
   uint32_t o0, o1, o2, o3;
   philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);

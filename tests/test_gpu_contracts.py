@@ -112,6 +112,7 @@ def test_prime_sample_counts_get_bounded_levels_and_the_same_picture(ctx, spp):
 
     scene = rtow.HostScene.cover(11, 1.5, False)
     cfg = rtow.make_config(120, 80, spp, 1, 50, seed=9, precision=rtow.F64_FAST)
+    ctx.upload(scene)  # (the item length aimed at depends on the resident scene: 10 for spheres, 16 for a mesh)
     pairs = (C.c_uint32 * 512)()
     n = rtow.lib().rtow_debug_schedule(ctx._h, C.byref(cfg), pairs, 256)
     sched = [(pairs[2 * i], pairs[2 * i + 1]) for i in range(n)]
