@@ -396,6 +396,35 @@ def other_config(name, a, dev, precision, steps, stress=False):
         "prim_tests_per_segment": round(st.prim_tests / max(st.segments, 1), 3),
         "roofline": roof, "roofline_valu": valu, "walk": walk,
     }
+    if not stress and kind in ("suzanne", "mesh100k"):
+        # What a caller waits for on a mesh (SURVEY.md §8d's region, the reference's own timer includes its tree build,
+        # src/render.cpp:141-188): rtow_render_rgb8 = upload + acceleration build + trace + write_color + D2H of
+        # the bytes, with the host SAH builder and with the device LBVH builder (both make the 4-wide image)
+        import ctypes as C
+        import numpy as np
+
+        L = rtow.lib()
+        host8 = np.zeros((H, W, 3), dtype=np.uint8)
+        e2e = {}
+        for bname, b in (("host_sah", rtow.BUILDER_HOST_SAH), ("device_lbvh", rtow.BUILDER_DEVICE_LBVH)):
+            ctx.set_builder(b)
+            n_calls = 2
+            ts = []
+            for i in range(n_calls + 1):
+                t0 = time.perf_counter()
+                rtow.check(L.rtow_render_rgb8(ctx._h, C.byref(scene.c), C.byref(cfg), host8.ctypes.data_as(C.c_void_p), None),
+                           "rtow_render_rgb8")
+                ts.append(time.perf_counter() - t0)
+            dt = sum(ts[1:]) / n_calls
+            bi2 = ctx.build_info()
+            e2e[bname] = {"value": round(W * H * spp / dt / 1e6, 3), "ms_per_call": round(dt * 1e3, 3),
+                          "build_ms": round(bi2.bvh_build_ms + bi2.grid_build_ms, 3), "upload_ms": round(bi2.upload_ms, 3),
+                          "bvh4_nodes": bi2.bvh4_nodes, "bvh4_node_bytes": bi2.bvh4_node_bytes}
+        ctx.set_builder(rtow.BUILDER_HOST_SAH)
+        best = max(e2e, key=lambda k: e2e[k]["value"])
+        line["end_to_end_rgb8"] = dict(e2e, best_builder=best, value_e2e=e2e[best]["value"],
+                                       region="rtow_render_rgb8(): upload + acceleration build + trace + reduce + "
+                                              "write_color + D2H of W*H*3 bytes, per call")
     ctx.close()
     del out
     return line

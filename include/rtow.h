@@ -69,7 +69,9 @@ extern "C" {
 #define RTOW_KERNEL_BVH4 4  /* triangle meshes: every lane walks a 4-wide BVH, nearest child
                                first, with a per-lane stack in LDS; the image (or the top of
                                its tree) is staged in LDS.  Falls back to BVH for scenes with
-                               spheres, for the f32 preview build and for the device builder */
+                               spheres, for the f32 preview build and for meshes beyond the
+                               format's limits (2^18 triangles).  Both builders make its image:
+                               the host collapses its SAH tree, the device builder its LBVH   */
 #define RTOW_KERNEL_REFTREE 5 /* opt-in exactness mode (RTOW_F64_STRICT only): every lane walks the REFERENCE's own
                                tree — median split of the insertion-ordered primitive array, leaves of 1..6 whose
                                boxes include the origin, float-rounded triangle boxes, signed-radius sphere boxes
@@ -200,7 +202,10 @@ int rtow_scene_upload(rtow_ctx *ctx, const rtow_scene_t *scene);
  *   DEVICE_LBVH Morton codes + radix sort + Karras' radix tree + refit, all on the GPU
  *               (csrc/rtow_build.hip) — for scenes rebuilt every frame; the uniform grid of the
  *               GRID kernel is then built on the GPU too (csrc/rtow_build_grid.hip, byte-identical
- *               to the host-built image)
+ *               to the host-built image), and for a triangle mesh the 4-wide image of the BVH4
+ *               kernel (greedy collapse of the radix tree level by level, breadth-first nodes,
+ *               planes rounded outwards, records in sorted order): nothing of the build runs on
+ *               the host
  * Images are bit-identical with either builder (the closest hit is tree-independent).
  * Takes effect at the next upload; the environment variable RTOW_BUILDER=host|device sets the
  * default of new contexts. */
@@ -217,7 +222,7 @@ typedef struct rtow_build_info_t {
                                including its two small read-backs */
   double grid_build_ms;     /* host wall time */
   double upload_ms;         /* whole rtow_scene_upload call */
-  int32_t bvh4_nodes;       /* 4-wide BVH image (triangle meshes, host builder): nodes, 0 = none */
+  int32_t bvh4_nodes;       /* 4-wide BVH image (triangle meshes, either builder): nodes, 0 = none */
   int32_t bvh4_image_bytes;
   /* RTOW_KERNEL_REFTREE (built at the first render that asks for it; 0 before): nodes of the reference's
    * tree and its "Total BVH stupid volume" diagnostic (src/render.cpp:36-50,148) */
@@ -287,6 +292,16 @@ int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out48);
  * `capacity_pairs` of them).  `ctx` may be NULL: the table of a new context (pure host arithmetic, usable
  * without a GPU). */
 int rtow_debug_schedule(rtow_ctx *ctx, const rtow_config_t *cfg, uint32_t *out_pairs, int32_t capacity_pairs);
+
+/* Diagnostic only (pure host arithmetic, usable without a GPU): the order in which the work queue of a render of
+ * `cfg` of `scene` runs its 64-pixel tiles (sphere scenes): perm_out[queue position] = tile (row-major over this
+ * rank's tile rows; the queue is consumed from its far end, so position 0 runs LAST), class_out[tile] = what the
+ * camera can see through the tile, 0 sky .. 1 only huge spheres (ground) .. 2 a small sphere .. 3 a dielectric one.
+ * Sky-only tiles run last: a launch ends one path after its queue runs dry unless the queue's end cannot start a long
+ * path (csrc/rtow_capi.cpp, tile_order).  variant 1 = the default of a context, 2 = glass not told apart.  Returns the
+ * number of tiles, 0 when the launch is not tiled or the scene has triangles. */
+int rtow_debug_tile_order(const rtow_scene_t *scene, const rtow_config_t *cfg, int32_t variant, uint32_t *perm_out,
+                          unsigned char *class_out, int32_t capacity, int32_t *tile_w_log2, int32_t *tile_h_log2);
 
 /* Diagnostic only: copies a resident scene image to the host (which: 0 BVH image, 1 grid image,
  * 2 / 3 the same of the RTOW_F32 build).  `out` NULL: size query.  The tests compare host-built

@@ -210,3 +210,112 @@ def test_device_grid_build_falls_back_like_the_host(ctx, dctx):
     ctx.upload(sc)
     dctx.upload(sc)
     assert ctx.build_info().grid_image_bytes == dctx.build_info().grid_image_bytes
+
+
+# ---- the 4-wide image of the BVH4 kernel, collapsed from the radix tree on the device (round 4) ---------------
+def _write_obj(path, tris):
+    with open(path, "w") as fh:
+        for tri in tris:
+            for p in tri:
+                fh.write(f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}\n")
+        for i in range(len(tris)):
+            fh.write(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n")
+
+
+@pytest.mark.parametrize("sm", [False, True])
+def test_device_built_bvh4_image_strict_is_bit_identical_to_oracle(dctx, tmp_path, monkeypatch, sm):
+    """`--builder device` no longer forces the binary walk on a triangle mesh: the 4-wide image (breadth-first
+    nodes, triangle records in sorted = leaf order, pairs of triangles per leaf) is collapsed from the LBVH on the
+    GPU.  Strict build against the oracle, bit for bit: suzanne (binary32 nodes, staged in LDS whole), suzanne
+    subdivided 2x2 as it is and shrunk and moved off the origin (binary16 nodes in the mesh's own frame), the
+    96,800-triangle mesh of BASELINE configs[4]; trip form and state-machine form of the kernel."""
+    sys.path.insert(0, str(REPO / "scripts"))
+    import make_mesh
+
+    if sm:
+        monkeypatch.setenv("RTOW_BVH4_SM", "1")
+    c = rtow.Context(0)
+    c.set_builder(rtow.BUILDER_DEVICE_LBVH)
+    try:
+        v, f = make_mesh.load(GOLDEN / "suzanne.obj")
+        cases = [("suzanne", GOLDEN / "suzanne.obj", 128, 968)]
+        tris = make_mesh.subdivide(v, f, 2)
+        _write_obj(tmp_path / "m2.obj", tris)
+        cases.append(("2x2", tmp_path / "m2.obj", 64, 3872))
+        _write_obj(tmp_path / "m2off.obj", tris * 0.55 + np.array((0.3125, -0.11, 0.27)))
+        cases.append(("2x2 off-origin", tmp_path / "m2off.obj", 64, 3872))
+        if not sm:
+            subprocess.run([sys.executable, str(REPO / "scripts" / "make_mesh.py"), str(tmp_path / "m10.obj"), "10"],
+                           check=True, capture_output=True)
+            cases.append(("10x10", tmp_path / "m10.obj", 64, 96800))
+        for k, (name, obj, node_bytes, nt) in enumerate(cases):
+            scene = rtow.HostScene.obj(obj, 16 / 9)
+            assert scene.c.n_triangles == nt
+            w, h, spp = (96, 54, 4) if nt < 50000 else (96, 54, 2)
+            cfg = rtow.make_config(w, h, spp, 2, 20, seed=5 + k, precision=rtow.F64_STRICT, kernel=rtow.KERNEL_AUTO)
+            img, st = c.render(scene, cfg)
+            bi = c.build_info()
+            assert bi.builder == rtow.BUILDER_DEVICE_LBVH and bi.bvh4_nodes > 0, name
+            # the node format follows the image's size by the host builder's rule (the radix tree has a few more nodes
+            # than the SAH tree: suzanne's 4-wide image misses the 160 KB of LDS by a few KB and takes binary16 nodes)
+            wide = bi.bvh4_image_bytes + (64 * bi.bvh4_nodes if bi.bvh4_node_bytes == 64 else 0)  # with 128-byte nodes
+            assert (bi.bvh4_node_bytes == 128) == (wide + 8 * 4096 <= 160 * 1024), (name, bi.bvh4_image_bytes, bi.bvh4_nodes)
+            if node_bytes == 64:
+                assert bi.bvh4_node_bytes == 64, name
+            assert st.kernel_used == rtow.KERNEL_BVH4, name  # AUTO takes the 4-wide walk with the device builder too
+            ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=8, accel=nt > 5000)
+            assert st.segments == ost.segments, name
+            assert np.array_equal(img, ref), f"{name}: {int((img != ref).sum())} values differ"
+            fast = rtow.make_config(w, h, spp, 2, 20, seed=5 + k, precision=rtow.F64_FAST)
+            fimg, fst = c.render(scene, fast)
+            assert fst.kernel_used == rtow.KERNEL_BVH4 and np.abs(fimg - ref).mean() / spp <= 2e-3, name
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 9, 40])
+def test_device_built_bvh4_tiny_meshes(dctx, tmp_path, n):
+    """One triangle (no inner node of the radix tree), a mesh that is ONE leaf (<= 2 triangles), just above, and
+    small ones: the first n triangles of suzanne, strict build against the oracle."""
+    sys.path.insert(0, str(REPO / "scripts"))
+    import make_mesh
+
+    v, f = make_mesh.load(GOLDEN / "suzanne.obj")
+    tris = make_mesh.subdivide(v, f, 1)[100:100 + n]
+    _write_obj(tmp_path / "t.obj", tris)
+    scene = rtow.HostScene.obj(tmp_path / "t.obj", 16 / 9)
+    cfg = rtow.make_config(64, 36, 4, 2, 10, seed=n, precision=rtow.F64_STRICT, kernel=rtow.KERNEL_BVH4)
+    img, st = dctx.render(scene, cfg)
+    assert st.kernel_used == rtow.KERNEL_BVH4 and dctx.build_info().bvh4_nodes >= 1
+    ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=2)
+    assert st.segments == ost.segments and np.array_equal(img, ref)
+
+
+def test_device_built_bvh4_coincident_triangles(dctx, tmp_path):
+    """Forty copies of one triangle and forty of another: equal Morton keys, the radix tree is decided by the index
+    tie-break alone and is a chain — the deepest 4-wide tree per triangle there is.  Against the binary walk of the
+    same scene (exact-t ties between coincident triangles are tree-dependent, so not against the oracle)."""
+    sys.path.insert(0, str(REPO / "scripts"))
+    import make_mesh
+
+    v, f = make_mesh.load(GOLDEN / "suzanne.obj")
+    t = make_mesh.subdivide(v, f, 1)
+    tris = np.concatenate([np.repeat(t[10:11], 40, axis=0), np.repeat(t[500:501], 40, axis=0), t[:60]])
+    _write_obj(tmp_path / "c.obj", tris)
+    scene = rtow.HostScene.obj(tmp_path / "c.obj", 16 / 9)
+    cfg4 = rtow.make_config(64, 36, 4, 2, 10, seed=3, precision=rtow.F64_FAST, kernel=rtow.KERNEL_BVH4)
+    a, sa = dctx.render(scene, cfg4)
+    assert sa.kernel_used == rtow.KERNEL_BVH4 and np.isfinite(a).all()
+    cfg2 = rtow.make_config(64, 36, 4, 2, 10, seed=3, precision=rtow.F64_FAST, kernel=rtow.KERNEL_BVH)
+    b, sb = dctx.render(scene, cfg2)
+    assert sb.kernel_used == rtow.KERNEL_BVH
+    assert np.abs(a - b).mean() / 4 <= 2e-3
+
+
+def test_device_builder_beyond_the_bvh4_limits_takes_the_binary_walk(dctx, tmp_path):
+    subprocess.run([sys.executable, str(REPO / "scripts" / "make_mesh.py"), str(tmp_path / "m17.obj"), "17"], check=True,
+                   capture_output=True)
+    big = rtow.HostScene.obj(tmp_path / "m17.obj", 16 / 9)
+    cfg = rtow.make_config(96, 54, 8, 2, 20, seed=13, precision=rtow.F64_FAST, kernel=rtow.KERNEL_BVH4)
+    a, st = dctx.render(big, cfg)
+    assert st.kernel_used == rtow.KERNEL_BVH and np.isfinite(a).all() and dctx.build_info().bvh4_nodes == 0
