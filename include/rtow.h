@@ -293,16 +293,6 @@ int rtow_debug_counters(rtow_ctx *ctx, unsigned long long *out48);
  * without a GPU). */
 int rtow_debug_schedule(rtow_ctx *ctx, const rtow_config_t *cfg, uint32_t *out_pairs, int32_t capacity_pairs);
 
-/* Diagnostic only (pure host arithmetic, usable without a GPU): the order in which the work queue of a render of
- * `cfg` of `scene` runs its 64-pixel tiles (sphere scenes): perm_out[queue position] = tile (row-major over this
- * rank's tile rows; the queue is consumed from its far end, so position 0 runs LAST), class_out[tile] = what the
- * camera can see through the tile, 0 sky .. 1 only huge spheres (ground) .. 2 a small sphere .. 3 a dielectric one.
- * Sky-only tiles run last: a launch ends one path after its queue runs dry unless the queue's end cannot start a long
- * path (csrc/rtow_capi.cpp, tile_order).  variant 1 = the default of a context, 2 = glass not told apart.  Returns the
- * number of tiles, 0 when the launch is not tiled or the scene has triangles. */
-int rtow_debug_tile_order(const rtow_scene_t *scene, const rtow_config_t *cfg, int32_t variant, uint32_t *perm_out,
-                          unsigned char *class_out, int32_t capacity, int32_t *tile_w_log2, int32_t *tile_h_log2);
-
 /* Diagnostic only: copies a resident scene image to the host (which: 0 BVH image, 1 grid image,
  * 2 / 3 the same of the RTOW_F32 build).  `out` NULL: size query.  The tests compare host-built
  * and device-built images byte for byte with it. */

@@ -262,8 +262,6 @@ struct Knobs {
                                   //   pixel, like the strict build).  5 / 10 / 20 / 25: 10.88 / 11.18 / 10.22 / 9.55 Gsamples/s on C2
   int sched_chunk_mesh = 16;      //   ... for a scene of triangles only (its walks are longer and resumable: fewer, longer items;
                                   //   4 / 8 / 16 / 32 samples: 4.60 / 4.64 / 4.69 / 4.68 Gsamples/s on C4, 2.29 / 2.30 / 2.32 / 2.32 on C5)
-  int tile_order = 1;             // RTOW_TILE_ORDER: 1 = the queue runs the tiles by what the camera sees through them (sky-only
-                                  //   tiles last, tiles that see glass first); 2 = glass not told apart; 0 = rows only (RTOW_SKY_EIGHTHS)
   int tail_bound = 0;             // RTOW_TAIL_BOUND (tests only): trips of the end-of-launch protocol before a wave gives up
                                   //   its samples (0 = the structural bound); a small value forces the RTOW_EHIP path
   void read() {
@@ -309,7 +307,6 @@ struct Knobs {
     sched_chunk = std::min(std::max(geti("RTOW_SCHED_CHUNK", 10), 0), 4096);
     sched_chunk_mesh = std::min(std::max(geti("RTOW_SCHED_CHUNK_MESH", 16), 0), 4096);
     tail_bound = std::max(geti("RTOW_TAIL_BOUND", 0), 0);
-    tile_order = geti("RTOW_TILE_ORDER", 1);
   }
 };
 
@@ -345,11 +342,7 @@ struct rtow_ctx {
     std::vector<double> sg, mg, tg;
     std::vector<int32_t> pk, pi;
     bool have_order = false;
-    rtow_camera_t cam{};
-    std::vector<unsigned char> s_glass, m_glass;  // per sphere / moving sphere: its material is a Dielectric
   } host_scene;
-  DevBuf tile_perm;  // queue position of a tile -> tile (tile_order())
-  long long tile_perm_key[8] = {-1, 0, 0, 0, 0, 0, 0, 0};  // what the table in tile_perm was made for (-1: nothing)
   DevBuf rtree;
   bool have_rtree = false;
   PinnedArena arena;     // staging of the scene uploads
@@ -432,7 +425,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
                     &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->rtree, &c->counters_init,
-                    &c->dropped, &c->tile_perm})
+                    &c->dropped})
     b->release();
   if (c->h_dropped) (void)hipHostFree(c->h_dropped);
   if (c->upload_ev) (void)hipEventDestroy(c->upload_ev);
@@ -496,7 +489,6 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
   } arena_scope(&c->arena);
   if (need & kNeedF32) need |= kNeedBvh | kNeedGrid;  // the binary32 images are derived from the binary64 ones
   c->built = 0;
-  c->tile_perm_key[0] = -1;
   c->have_scene = false;
   c->have_rtree = false;
   c->build_info.ref_tree_nodes = 0;
@@ -507,11 +499,6 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
     h.sg.assign(s->sphere_geom, s->sphere_geom + 4 * (size_t)s->n_spheres);
     h.mg.assign(s->moving_geom, s->moving_geom + 8 * (size_t)s->n_moving);
     h.tg.assign(s->triangle_geom, s->triangle_geom + 9 * (size_t)s->n_triangles);
-    h.cam = s->camera;
-    h.s_glass.resize((size_t)s->n_spheres);
-    h.m_glass.resize((size_t)s->n_moving);
-    for (int i = 0; i < s->n_spheres; ++i) h.s_glass[i] = s->materials[s->sphere_mat[i]].kind == RTOW_MAT_DIELECTRIC;
-    for (int i = 0; i < s->n_moving; ++i) h.m_glass[i] = s->materials[s->moving_mat[i]].kind == RTOW_MAT_DIELECTRIC;
     h.have_order = s->prim_kind && s->prim_index;
     if (h.have_order) {
       for (int i = 0; i < s->n_prims; ++i) {
@@ -1092,167 +1079,6 @@ static void tile_shape(const rtow_config_t *cfg, int rows, uint32_t &th, uint32_
   }
 }
 
-// The order in which the queue runs the tiles, from what the camera sees through each one: every sphere's silhouette
-// cone (widened for the lens) marks the tiles whose own cone of directions (widened for the jitter) it can reach —
-// 3 = a dielectric sphere (paths can run to the bounce limit inside it), 2 = another small sphere, 1 = only huge
-// spheres (the ground), 0 = nothing (sky: one segment per sample).  Costly classes first (the queue is consumed from
-// its far end), rows top-down inside a class, sky last.  Why: a launch ends one PATH after its queue runs dry (a lone
-// wave's 50-bounce path is 0.3 ms), unless the last stretch of the queue is work that cannot start such a path; "the
-// top eighth of the image" (RTOW_SKY_EIGHTHS) is that only where no sphere reaches into it — in the cover scene the
-// three big spheres do — and it is an eighth of the rows whatever the scene, where the sky-only tiles are a fifth of
-// this one.  It matters most where a launch is short: one rank's share of configs[2] at N = 8.
-// A hint: it never changes what is rendered, only when.  perm[queue position of the tile] = tile (row-major over
-// this rank's tile rows).
-static void tile_order(const rtow_ctx::HostSceneCopy &h, int variant, const rtow_config_t *cfg, uint32_t th, uint32_t tw, int rows,
-                       std::vector<uint32_t> &perm, std::vector<unsigned char> *classes = nullptr) {
-  const uint32_t tpr = (uint32_t)cfg->image_width >> tw, ntr = (uint32_t)rows >> th, nt = tpr * ntr;
-  std::vector<int32_t> row_list((size_t)rows);
-  rtow_local_row_list(cfg, row_list.data(), rows);
-  std::vector<unsigned char> cls(nt, 0), out(nt, 0);
-  const rtow_camera_t &cam = h.cam;
-  const int W = cfg->image_width, H = cfg->image_height;
-  const uint32_t tile_w = 1u << tw, tile_h = 1u << th;
-  // Conservative screen rectangle of a sphere (a few dozen operations per sphere, not rays per tile: the table is
-  // made inside the first render after every upload).  In the camera's frame (u, v, -w) a viewport point (s, t) has
-  // the direction ((s - 1/2) |H|, (t - 1/2) |V|, fd); the sphere's extent along one image axis is the angle to its
-  // centre in that axis' plane +- the half-angle it subtends there.
-  auto dot3 = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
-  const double lenH = std::sqrt(dot3(cam.horizontal, cam.horizontal)), lenV = std::sqrt(dot3(cam.vertical, cam.vertical));
-  double mid[3];
-  for (int k = 0; k < 3; ++k) mid[k] = cam.lower_left_corner[k] + 0.5 * cam.horizontal[k] + 0.5 * cam.vertical[k] - cam.origin[k];
-  const double fd = -dot3(mid, cam.w);  // the viewport lies fd along -w
-  const bool cam_ok = lenH > 0.0 && lenV > 0.0 && fd > 0.0 && std::isfinite(lenH + lenV + fd);
-  // global image row -> this rank's tile row (or -1), for marking rectangles given in image rows
-  std::vector<int32_t> tile_row_of((size_t)std::max(H, 1), -1);
-  for (int lr = 0; lr < rows; ++lr)
-    if (row_list[(size_t)lr] >= 0 && row_list[(size_t)lr] < H) tile_row_of[(size_t)row_list[(size_t)lr]] = lr >> th;
-  // a tile as the camera sees it: the direction through its centre and a bound on the angle between that and the
-  // direction through any of its points (two viewport points are at least fd from the eye: angle <= distance / fd)
-  const double wm = (double)std::max(W - 1, 1), hm = (double)std::max(H - 1, 1);
-  const double tile_beta = cam_ok ? 0.5 * std::sqrt(((double)tile_w + 1.0) * ((double)tile_w + 1.0) * lenH * lenH / (wm * wm) +
-                                                    ((double)tile_h + 1.0) * ((double)tile_h + 1.0) * lenV * lenV / (hm * hm)) / fd
-                                  : 0.0;
-  // marks the tiles of the viewport rectangle [s0, s1] x [t0, t1] that the cone (axis `ax`, unit; half-angle alpha) of
-  // a sphere's silhouette can reach: the rectangle bounds the search, the cone test decides (a sphere's outline is a
-  // disc, and the three big spheres' rectangles would claim a third more sky than their discs)
-  auto mark = [&](double s0, double s1, double t0, double t1, int k, const double *ax, double alpha) {
-    // columns j with (j + [0, 1)) / (W - 1) in [s0, s1]; rows i with (H - 1 - i + [0, 1)) / (H - 1) in [t0, t1]
-    const double j0 = std::floor(s0 * wm - 1.0), j1 = std::ceil(s1 * wm + 1.0);
-    const double i0 = std::floor(hm - t1 * hm - 1.0), i1 = std::ceil(hm - t0 * hm + 1.0);
-    const int ja = (int)std::min(std::max(j0, 0.0), (double)(W - 1)), jb = (int)std::min(std::max(j1, 0.0), (double)(W - 1));
-    const int ia = (int)std::min(std::max(i0, 0.0), (double)(H - 1)), ib = (int)std::min(std::max(i1, 0.0), (double)(H - 1));
-    if (j1 < 0.0 || j0 > (double)(W - 1) || i1 < 0.0 || i0 > (double)(H - 1)) return;
-    const uint32_t ca = (uint32_t)ja >> tw, cb = std::min<uint32_t>((uint32_t)jb >> tw, tpr - 1u);
-    const double reach = alpha + tile_beta;
-    const double cos_reach = reach >= 3.14159 ? -2.0 : std::cos(reach);
-    int last = -1;
-    for (int i = ia; i <= ib; ++i) {
-      const int tr = tile_row_of[(size_t)i];
-      if (tr < 0 || tr == last || (uint32_t)tr >= ntr) continue;
-      last = tr;
-      const double yc = 0.5 * ((double)row_list[(size_t)tr << th] + (double)row_list[((size_t)tr << th) + tile_h - 1] + 1.0);
-      const double vt = (hm - yc + 0.5) / hm;  // (centre of the rows' sample range: row i covers (H-1-i + [0,1)) / (H-1))
-      for (uint32_t tc = ca; tc <= cb; ++tc) {
-        unsigned char &cell = cls[(size_t)tr * tpr + tc];
-        if (cell >= (unsigned char)k) continue;
-        const double us = ((double)(tc << tw) + 0.5 * (double)tile_w) / wm;
-        double d[3], dd = 0.0, da = 0.0;
-        for (int q = 0; q < 3; ++q) {
-          d[q] = cam.lower_left_corner[q] + us * cam.horizontal[q] + vt * cam.vertical[q] - cam.origin[q];
-          dd += d[q] * d[q];
-          da += d[q] * ax[q];
-        }
-        if (da >= cos_reach * std::sqrt(dd)) cell = (unsigned char)k;
-      }
-    }
-  };
-  const double kPi2 = 1.5707963267948966;
-  auto extent = [&](double p, double z, double r, double scale, double &lo, double &hi) {
-    // one image axis: centre at (p, z) in that axis' plane (z forward), radius r; viewport coordinate = 1/2 + tan(angle) * scale
-    const double dist = std::sqrt(p * p + z * z);
-    if (!(dist > r)) {  // the camera is inside the sphere's shadow on this axis: everything
-      lo = -1e30;
-      hi = 1e30;
-      return;
-    }
-    const double th0 = std::atan2(p, z), al = std::asin(std::min(1.0, r / dist));
-    const double a0 = th0 - al, a1 = th0 + al;
-    lo = a0 <= -kPi2 ? -1e30 : (a0 >= kPi2 ? 1e30 : 0.5 + std::tan(a0) * scale);
-    hi = a1 >= kPi2 ? 1e30 : (a1 <= -kPi2 ? -1e30 : 0.5 + std::tan(a1) * scale);
-  };
-  auto sphere_rect = [&](const double *cc, double r, double &s0, double &s1, double &t0, double &t1, double *ax, double &alpha) {
-    double rel[3];
-    for (int k = 0; k < 3; ++k) rel[k] = cc[k] - cam.origin[k];
-    const double px = dot3(rel, cam.u), py = dot3(rel, cam.v), pz = -dot3(rel, cam.w);
-    r = std::fabs(r) * 1.0001 + 1e-9;
-    const double dist = std::sqrt(px * px + py * py + pz * pz);
-    if (pz + r <= 0.0 && dist > r) return false;  // wholly behind the camera
-    extent(px, pz, r, fd / lenH, s0, s1);
-    extent(py, pz, r, fd / lenV, t0, t1);
-    // the silhouette cone as seen from ANY point of the lens (radius lr around the eye), plus the angle by which a ray
-    // through a viewport point turns when its origin moves across the lens (<= lr / fd): depth of field cannot carry a
-    // sphere into a tile this cone does not reach
-    const double lr = std::fabs(cam.lens_radius);
-    alpha = dist - lr > r + lr ? std::asin((r + lr) / (dist - lr)) + lr / fd : 4.0;  // (inside the sphere: every direction)
-    for (int k = 0; k < 3; ++k) ax[k] = dist > 0.0 ? rel[k] / dist : 0.0;
-    return s0 <= s1 && t0 <= t1;
-  };
-  if (!cam_ok) {
-    std::fill(cls.begin(), cls.end(), (unsigned char)2);  // (no usable camera frame: nothing is "sky")
-  } else {
-    for (size_t i = 0; i < h.sg.size() / 4; ++i) {
-      double s0, s1, t0, t1, ax[3], alpha;
-      const double r = h.sg[4 * i + 3];
-      if (sphere_rect(&h.sg[4 * i], r, s0, s1, t0, t1, ax, alpha))
-        mark(s0, s1, t0, t1, std::fabs(r) > 100.0 ? 1 : (h.s_glass[i] ? 3 : 2), ax, alpha);
-    }
-    for (size_t i = 0; i < h.mg.size() / 8; ++i) {
-      // a moving centre: the cone around the MIDDLE of its path, widened by the angle half the path subtends
-      const double *m = &h.mg[8 * i];
-      const double r = m[6];  // (moving_geom: c0 xyz, c1 xyz, r)
-      double a0, a1, b0, b1, c0, c1s, d0, d1, axa[3], axb[3], ala, alb;
-      const bool ea = sphere_rect(m, r, a0, a1, b0, b1, axa, ala), eb = sphere_rect(m + 3, r, c0, c1s, d0, d1, axb, alb);
-      const int k = std::fabs(r) > 100.0 ? 1 : (h.m_glass[i] ? 3 : 2);
-      if (!ea && !eb) continue;
-      if (!(ea && eb)) {  // one end behind the camera: be generous
-        const double everywhere[3] = {0, 0, 0};
-        mark(-1e30, 1e30, -1e30, 1e30, k, everywhere, 4.0);
-        continue;
-      }
-      // the centre sweeps the arc between the two end directions: a cone around the bisector with half-angle
-      // (arc / 2 + the larger of the two silhouettes) contains every position's cone
-      double mid_ax[3], mm = 0.0, cosab = 0.0;
-      for (int q = 0; q < 3; ++q) {
-        mid_ax[q] = axa[q] + axb[q];
-        mm += mid_ax[q] * mid_ax[q];
-        cosab += axa[q] * axb[q];
-      }
-      if (mm <= 0.0) {
-        const double everywhere[3] = {0, 0, 0};
-        mark(-1e30, 1e30, -1e30, 1e30, k, everywhere, 4.0);
-        continue;
-      }
-      for (int q = 0; q < 3; ++q) mid_ax[q] /= std::sqrt(mm);
-      const double arc = std::acos(std::min(1.0, std::max(-1.0, cosab)));
-      mark(std::min(a0, c0), std::max(a1, c1s), std::min(b0, d0), std::max(b1, d1), k, mid_ax, 0.5 * arc + std::max(ala, alb) + 1e-9);
-    }
-  }
-  (void)tile_w;
-  (void)tile_h;
-  out = cls;  // (no dilation: the jitter is in the tile's angular radius, the lens in every sphere's cone)
-  if (classes) *classes = out;
-  perm.resize(nt);
-  uint32_t pos = 0;
-  for (int k = 0; k <= 3; ++k) {  // lowest positions are consumed last
-    for (uint32_t tr = ntr; tr-- > 0;)  // inside a class the TOP rows go first, i.e. sit at the highest positions
-      for (uint32_t tc = tpr; tc-- > 0;) {
-        int kk = out[tr * tpr + tc];
-        if (variant == 2 && kk == 3) kk = 2;  // (variant 2: the dielectric tiles are not told apart)
-        if (kk == k) perm[pos++] = tr * tpr + tc;
-      }
-  }
-}
-
 static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums, void *hip_stream,
                          rtow_stats_t *stats, const LevelPlan &plan, int lvl_first, int lvl_count, int accumulate);
 
@@ -1528,20 +1354,6 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   {
     const int eighths = c->knobs.sky_eighths;  // the top eighth of the image is traced last (RTOW_SKY_EIGHTHS: 0..8)
     P.sky_rows = th ? P.n_tile_rows * (uint32_t)eighths / 8u : 0u;
-  }
-  P.tile_perm = nullptr;
-  if (th && c->knobs.tile_order && c->host_scene.tg.empty() && (c->host_scene.sg.size() + c->host_scene.mg.size()) > 0) {
-    const long long key[8] = {1, cfg->image_width, cfg->image_height, cfg->rank, cfg->nranks, cfg->tile_rows, (long long)th,
-                              c->knobs.tile_order};
-    if (std::memcmp(key, c->tile_perm_key, sizeof key) != 0) {  // (per scene and image shape: made once, kept)
-      std::vector<uint32_t> perm;
-      tile_order(c->host_scene, c->knobs.tile_order, cfg, th, tw, rows, perm);
-      if ((rc = c->tile_perm.ensure(perm.size() * sizeof(uint32_t)))) return rc;
-      HIPCHK(hipMemcpyAsync(c->tile_perm.p, perm.data(), perm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));  // (`perm` is pageable host memory that goes out of scope)
-      std::memcpy(c->tile_perm_key, key, sizeof key);
-    }
-    P.tile_perm = (const uint32_t *)c->tile_perm.p;
   }
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
@@ -1848,39 +1660,6 @@ int rtow_render_rgb8(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_t
 }
 int rtow_render_device_rgb8(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb8, void *hip_stream, rtow_stats_t *stats) {
   return guarded("rtow_render_device_rgb8", [&] { return impl_render_device_rgb8(c, cfg, d_rgb8, hip_stream, stats); });
-}
-// (diagnostic / tests; pure host arithmetic, usable without a GPU) the tile order of a render of `cfg` of `scene`:
-// perm_out[queue position of the tile] = tile, class_out[tile] = 0 sky .. 3 glass.  Returns the number of tiles
-// (0: the launch is not tiled, or the scene has triangles: rows-only order), writes at most `capacity` of each.
-int rtow_debug_tile_order(const rtow_scene_t *scene, const rtow_config_t *cfg, int32_t variant, uint32_t *perm_out,
-                          unsigned char *class_out, int32_t capacity, int32_t *tile_w_log2, int32_t *tile_h_log2) {
-  return guarded("rtow_debug_tile_order", [&]() -> int {
-    int rc = validate_scene(scene);
-    if (rc) return rc;
-    if ((rc = validate_cfg(cfg))) return rc;
-    rtow_ctx::HostSceneCopy h;
-    h.sg.assign(scene->sphere_geom, scene->sphere_geom + 4 * (size_t)scene->n_spheres);
-    h.mg.assign(scene->moving_geom, scene->moving_geom + 8 * (size_t)scene->n_moving);
-    h.cam = scene->camera;
-    h.s_glass.resize((size_t)scene->n_spheres);
-    h.m_glass.resize((size_t)scene->n_moving);
-    for (int i = 0; i < scene->n_spheres; ++i) h.s_glass[i] = scene->materials[scene->sphere_mat[i]].kind == RTOW_MAT_DIELECTRIC;
-    for (int i = 0; i < scene->n_moving; ++i) h.m_glass[i] = scene->materials[scene->moving_mat[i]].kind == RTOW_MAT_DIELECTRIC;
-    const int rows = rtow_local_rows(cfg);
-    uint32_t th = 0, tw = 0;
-    tile_shape(cfg, rows, th, tw);
-    if (tile_w_log2) *tile_w_log2 = (int32_t)tw;
-    if (tile_h_log2) *tile_h_log2 = (int32_t)th;
-    if (!th || scene->n_triangles > 0 || scene->n_spheres + scene->n_moving == 0) return 0;
-    std::vector<uint32_t> perm;
-    std::vector<unsigned char> cls;
-    tile_order(h, variant, cfg, th, tw, rows, perm, &cls);
-    for (size_t i = 0; i < perm.size() && (int32_t)i < capacity; ++i) {
-      if (perm_out) perm_out[i] = perm[i];
-      if (class_out) class_out[i] = cls[i];
-    }
-    return (int)perm.size();
-  });
 }
 int rtow_debug_schedule(rtow_ctx *c, const rtow_config_t *cfg, uint32_t *out, int32_t capacity_pairs) {
   return guarded("rtow_debug_schedule", [&] { return impl_debug_schedule(c, cfg, out, capacity_pairs); });

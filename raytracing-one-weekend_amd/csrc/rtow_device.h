@@ -117,7 +117,6 @@ struct TraceParams {
   FastDiv div_tpr;         // tiles per row = W >> tile_w_log2
   uint32_t div_tpr_n;      // the divisor itself
   uint32_t n_tile_rows, sky_rows;  // tiled order: tile rows of this rank, and how many of the top ones come last
-  const uint32_t *tile_perm;       // not NULL: queue position of a tile -> tile (row-major index); replaces the rule above
   double *partials;        // [nstreams][local_rows*W][3]
   uint32_t *stack;         // [max_child_rays][n_lanes] material index per bounce
   uint32_t *spill;         // BVH4 kernel: traversal stack entries beyond the LDS part, [entry][n_lanes]

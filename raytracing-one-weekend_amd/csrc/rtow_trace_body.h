@@ -192,16 +192,12 @@ __device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp,
     const uint32_t g64 = qi >> 6, w = qi & 63u;
     const uint32_t t = fastdiv(g64, FastDiv{kp->div_ns.magic, kp->div_ns.shift});
     k = g64 - t * (uint32_t)kp->nstreams;
-    // (a table made by the host from what the camera sees through each tile, rtow_capi.cpp::tile_order: the tiles
-    // whose paths can be long go first, the ones that see only sky last)
-    const uint32_t *perm = kp->tile_perm;
-    const uint32_t tq = perm ? perm[t] : t;
-    const uint32_t trq = fastdiv(tq, FastDiv{kp->div_tpr.magic, kp->div_tpr.shift});  // tile row by queue position
-    const uint32_t tc = tq - trq * (kp->div_tpr_n);
+    const uint32_t trq = fastdiv(t, FastDiv{kp->div_tpr.magic, kp->div_tpr.shift});  // tile row by queue position
+    const uint32_t tc = t - trq * (kp->div_tpr_n);
     // Tile rows are consumed from the highest position down.  Positions >= sky_rows hold the
     // rows below the top band, top-down (the horizon rows of an outdoor scene — its costliest —
     // go first); the top band (sky_rows tile rows, typically one-segment paths) comes last.
-    const uint32_t tr = perm ? trq : (trq >= kp->sky_rows ? kp->sky_rows + (kp->n_tile_rows - 1u - trq) : trq);
+    const uint32_t tr = trq >= kp->sky_rows ? kp->sky_rows + (kp->n_tile_rows - 1u - trq) : trq;
     lp = ((tr * kp->div_tpr_n + tc) << 6) | w;
     lr = (tr << kp->tile_h_log2) + (w >> kp->tile_w_log2);
     ip.j = (tc << kp->tile_w_log2) + (w & ((1u << kp->tile_w_log2) - 1u));

@@ -107,7 +107,7 @@ EXPORTS = [
     "rtow_debug_schedule", "rtow_host_scene_cover_model", "rtow_host_scene_obj_model",
     "rtow_multi_create", "rtow_multi_set_builder", "rtow_multi_upload", "rtow_multi_build_info",
     "rtow_multi_render", "rtow_multi_destroy", "rtow_host_reftree_info",
-    "rtow_render_device_rgb8", "rtow_multi_render_rgb8", "rtow_debug_tile_order",
+    "rtow_render_device_rgb8", "rtow_multi_render_rgb8",
 ]
 
 

@@ -272,69 +272,3 @@ def test_product_reference_tree_builder_matches_the_oracles_tree(which):
     if survey is not None:
         assert float("%.6g" % vol.value) == survey
     assert 0 <= depth.value < 48
-
-
-def _tile_order(scene, cfg, variant=1):
-    L = rtow.lib()
-    L.rtow_debug_tile_order.argtypes = [C.POINTER(rtow.Scene), C.POINTER(rtow.Config), C.c_int32, C.POINTER(C.c_uint32),
-                                        C.POINTER(C.c_ubyte), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    cap = 1 << 16
-    perm, cls = (C.c_uint32 * cap)(), (C.c_ubyte * cap)()
-    tw, th = C.c_int32(), C.c_int32()
-    n = L.rtow_debug_tile_order(C.byref(scene.c), C.byref(cfg), variant, perm, cls, cap, C.byref(tw), C.byref(th))
-    assert n >= 0
-    return np.array(perm[:n]), np.array(cls[:n]), tw.value, th.value
-
-
-@pytest.mark.parametrize("moving,nranks,rank,tile_rows", [(False, 1, 0, 8), (True, 1, 0, 8), (False, 8, 3, 4), (False, 2, 1, 8)])
-def test_tile_order_is_a_permutation_with_a_conservative_sky_class(moving, nranks, rank, tile_rows):
-    """The queue's tile order (pure host arithmetic): a permutation of this rank's tiles, classes ascending with the
-    queue position (the queue is consumed from its far end: sky-only tiles LAST), and conservative — no camera ray
-    through a tile classed sky (0) hits any sphere, checked by brute force over a lattice of pinhole rays per tile; a
-    tile classed ground-only (1) sees no small sphere.  An eighth of the cover image is such sky (more than the top rows alone: the big spheres reach into those)."""
-    scene = rtow.HostScene.cover(11, 1.5, moving)
-    W, H = 1200, 800
-    cfg = rtow.make_config(W, H, 100, 10, 50, rank=rank, nranks=nranks, tile_rows=tile_rows)
-    perm, cls, tw, th = _tile_order(scene, cfg)
-    rows = rtow.local_rows(cfg)
-    tpr, ntr = W >> tw, len(rows) >> th
-    assert len(perm) == tpr * ntr and sorted(perm) == list(range(tpr * ntr))
-    assert (np.diff(cls[perm].astype(int)) >= 0).all()  # position 0 (runs last) is the lowest class
-    sky = np.flatnonzero(cls == 0)
-    assert len(sky) > 0.12 * len(cls) and (cls == 3).any() and (cls == 1).any()
-    # brute force: pinhole rays through a 5x5 lattice of every sky / ground-only tile (corners included)
-    s = scene.c
-    cam = s.camera
-    o = np.array(cam.origin[:])
-    llc, hor, ver = np.array(cam.lower_left_corner[:]), np.array(cam.horizontal[:]), np.array(cam.vertical[:])
-    cen, rad = [], []
-    for i in range(s.n_spheres):
-        cen.append(s.sphere_geom[4 * i:4 * i + 3]); rad.append(s.sphere_geom[4 * i + 3])
-    for i in range(s.n_moving):
-        for k in (0, 3):
-            cen.append(s.moving_geom[8 * i + k:8 * i + k + 3]); rad.append(s.moving_geom[8 * i + 6])
-    cen, rad = np.array(cen), np.array(rad)
-    small = np.abs(rad) < 100
-    rng = np.random.default_rng(0)
-    check = np.concatenate([sky, rng.choice(np.flatnonzero(cls == 1), 200)])
-    lat = np.linspace(0.0, 1.0, 5)
-    for t in check:
-        tr, tc = divmod(int(t), tpr)
-        x0, y0 = tc << tw, rows[tr << th]
-        px = x0 + lat * (1 << tw)
-        py = y0 + lat * (1 << th)
-        u = (px / (W - 1))[None, :].repeat(5, 0).ravel()
-        v = ((H - 1 - py) / (H - 1))[:, None].repeat(5, 1).ravel()
-        d = llc[None, :] + u[:, None] * hor[None, :] + v[:, None] * ver[None, :] - o[None, :]
-        oc = o[None, :] - cen                                        # [S, 3]
-        a = (d * d).sum(1)[:, None]                                  # [R, 1]
-        hb = d @ oc.T                                                # [R, S]
-        cq = ((oc * oc).sum(1) - rad * rad)[None, :]
-        hit = (hb * hb - a * cq >= 0) & ~((hb > 0) & (cq > 0))
-        if cls[t] == 0:
-            assert not hit.any(), (t, tr, tc)
-        else:
-            assert not hit[:, small].any(), (t, tr, tc)
-    # triangles: rows-only order
-    mesh = rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9)
-    assert len(_tile_order(mesh, rtow.make_config(640, 360, 4, 1, 20))[0]) == 0
