@@ -111,42 +111,92 @@ struct Builder {
       make_leaf();
       return;
     }
-    // binned SAH over the three axes
+    // binned SAH over the three axes: ONE pass over the primitives fills the bins of all three (round 4: the three
+    // separate passes were a third of the 96.8k-triangle mesh's build; same arithmetic, same tree)
     int best_axis = -1, best_split = -1;
     double best_cost = INFINITY;
+    double c0s[3], scales[3];
+    bool use[3];
     for (int ax = 0; ax < 3; ++ax) {
-      const double c0 = cb.mn[ax], c1 = cb.mx[ax];
-      if (!(c1 > c0)) continue;
-      Box bins[kBins];
-      int cnt[kBins];
+      c0s[ax] = cb.mn[ax];
+      use[ax] = cb.mx[ax] > cb.mn[ax];
+      scales[ax] = use[ax] ? kBins / (cb.mx[ax] - cb.mn[ax]) : 0.0;
+    }
+    auto bin_of = [&](int p, int ax) {
+      int bi = (int)((cen[(size_t)p * 3 + ax] - c0s[ax]) * scales[ax]);
+      return std::min(std::max(bi, 0), kBins - 1);
+    };
+    constexpr int kSmall = 16;
+    if (n <= kSmall) {
+      // Few primitives (most nodes of a tree are down here): the same splits evaluated without the 48 bins — the
+      // primitives are ordered by their bin along the axis and a split is tried after every bin that holds something
+      // (a split after an EMPTY bin has the cost of the one before it and never wins `<`).  Unions of boxes are
+      // min / max, so the areas — and the tree — are the binned sweep's, bit for bit; resetting and sweeping 3 x 16
+      // bins per node was a third of the 96.8k-triangle mesh's build.
+      for (int ax = 0; ax < 3; ++ax) {
+        if (!use[ax]) continue;
+        int bi[kSmall], ord[kSmall];
+        for (int i = 0; i < n; ++i) {
+          bi[i] = bin_of(order[lo + i], ax);
+          int j = i;
+          for (; j > 0 && bi[ord[j - 1]] > bi[i]; --j) ord[j] = ord[j - 1];
+          ord[j] = i;
+        }
+        double right_area[kSmall];  // union of the primitives at sorted positions >= j
+        Box acc;
+        acc.reset();
+        for (int j = n - 1; j >= 1; --j) {
+          acc.grow(pb[order[lo + ord[j]]]);
+          right_area[j] = acc.half_area();
+        }
+        acc.reset();
+        for (int j = 0; j < n - 1; ++j) {
+          acc.grow(pb[order[lo + ord[j]]]);
+          const int k = bi[ord[j]];
+          if (bi[ord[j + 1]] == k || k >= kBins - 1) continue;  // the bin is not complete yet / no split after the last bin
+          const double cost = acc.half_area() * (j + 1) + right_area[j + 1] * (n - 1 - j);
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_axis = ax;
+            best_split = k;
+          }
+        }
+      }
+    } else {
+    Box bins[3][kBins];
+    int cnt[3][kBins];
+    for (int ax = 0; ax < 3; ++ax)
       for (int k = 0; k < kBins; ++k) {
-        bins[k].reset();
-        cnt[k] = 0;
+        bins[ax][k].reset();
+        cnt[ax][k] = 0;
       }
-      const double scale = kBins / (c1 - c0);
-      for (int i = lo; i < hi; ++i) {
-        const int p = order[i];
-        int bi = (int)((cen[(size_t)p * 3 + ax] - c0) * scale);
-        bi = std::min(std::max(bi, 0), kBins - 1);
-        bins[bi].grow(pb[p]);
-        cnt[bi]++;
+    for (int i = lo; i < hi; ++i) {
+      const int p = order[i];
+      for (int ax = 0; ax < 3; ++ax) {
+        if (!use[ax]) continue;
+        const int bi = bin_of(p, ax);
+        bins[ax][bi].grow(pb[p]);
+        cnt[ax][bi]++;
       }
+    }
+    for (int ax = 0; ax < 3; ++ax) {
+      if (!use[ax]) continue;
       double right_area[kBins];
       int right_cnt[kBins];
       Box acc;
       acc.reset();
       int c = 0;
       for (int k = kBins - 1; k >= 1; --k) {
-        acc.grow(bins[k]);
-        c += cnt[k];
+        acc.grow(bins[ax][k]);
+        c += cnt[ax][k];
         right_area[k] = acc.half_area();
         right_cnt[k] = c;
       }
       acc.reset();
       c = 0;
       for (int k = 0; k < kBins - 1; ++k) {
-        acc.grow(bins[k]);
-        c += cnt[k];
+        acc.grow(bins[ax][k]);
+        c += cnt[ax][k];
         if (c == 0 || right_cnt[k + 1] == 0) continue;
         const double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
         if (cost < best_cost) {
@@ -155,6 +205,7 @@ struct Builder {
           best_split = k;
         }
       }
+    }
     }
     int mid = -1;
     if (best_axis >= 0) {

@@ -53,7 +53,8 @@ inline double half_value(uint16_t h) {
   double v = e == 0 ? std::ldexp((double)m, -24) : (e == 31 ? (m ? NAN : INFINITY) : std::ldexp((double)(m | 1024), e - 25));
   return (h & 0x8000) ? -v : v;
 }
-// the largest binary16 <= x (dir < 0) or the smallest >= x (dir > 0)
+// the largest binary16 <= x (dir < 0) or the smallest >= x (dir > 0).  Integer arithmetic on the binary64 pattern
+// (the frexp / ldexp / ceil form this replaces was 19 ms of the 96.8k-triangle mesh's image: 646,000 planes).
 inline uint16_t half_directed(double x, int dir) {
   if (std::isnan(x)) return 0x7e00;
   const bool neg = std::signbit(x);
@@ -63,11 +64,17 @@ inline uint16_t half_directed(double x, int dir) {
   if (a == 0.0) return sign;
   if (std::isinf(a)) return sign | 0x7c00;
   if (a > 65504.0) return sign | (mag_up ? 0x7c00 : 0x7bff);
-  int e;
-  std::frexp(a, &e);                      // a in [2^(e-1), 2^e)
-  const int E = std::max(e - 1, -14);     // denormals share the exponent of the smallest normal
-  const double q = std::ldexp(a, 10 - E); // a in units of its ulp: exact
-  const uint32_t qi = (uint32_t)(mag_up ? std::ceil(q) : std::floor(q));  // 0 .. 2048
+  uint64_t b;
+  std::memcpy(&b, &a, sizeof b);
+  const int be = (int)(b >> 52);  // biased exponent; 0 = a binary64 denormal (< 2^-1022: far below binary16's 2^-24)
+  if (be == 0) return sign | (uint16_t)(mag_up ? 1 : 0);
+  const int e = be - 1023;                                       // a = m * 2^(e - 52), m in [2^52, 2^53)
+  const uint64_t m = (b & ((1ull << 52) - 1ull)) | (1ull << 52);
+  const int E = std::max(e, -14);  // denormals share the exponent of the smallest normal
+  const int sh = 42 + (E - e);     // a in units of its binary16 ulp: q = a * 2^(10 - E) = m >> sh, exactly
+  uint64_t q = sh >= 64 ? 0ull : (m >> sh);
+  const bool inexact = sh >= 64 ? true : (m & ((1ull << sh) - 1ull)) != 0ull;
+  const uint32_t qi = (uint32_t)q + ((mag_up && inexact) ? 1u : 0u);  // 0 .. 2048
   // (a carry, qi = 2048, lands in the next exponent by plain addition; so does 1024 from the denormals)
   const uint32_t bits = (E == -14 && qi < 1024u) ? qi : (((uint32_t)(E + 15) << 10) + (qi - 1024u));
   return sign | (uint16_t)std::min<uint32_t>(bits, 0x7c00u);

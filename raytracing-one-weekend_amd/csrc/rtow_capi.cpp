@@ -312,7 +312,10 @@ struct Knobs {
 
 // what a scene upload builds besides the record arrays: rtow_scene_upload builds everything (the scene stays
 // resident for any later render); rtow_render / rtow_render_rgb8 know their config and build what its kernel reads
-constexpr unsigned kNeedBvh = 1u, kNeedGrid = 2u, kNeedF32 = 4u, kNeedAll = 7u;
+// kNeedBvh: the binary threaded image (BVH kernel); kNeedBvh4: the 4-wide image of a triangle mesh (BVH4 kernel) — a
+// render that walks the one does not pay for the other (the 96.8k-triangle mesh: 20 ms of host work and 10 MB of
+// upload less per rtow_render call)
+constexpr unsigned kNeedBvh = 1u, kNeedGrid = 2u, kNeedF32 = 4u, kNeedBvh4 = 8u, kNeedAll = 15u;
 
 struct rtow_ctx {
   int device = 0;
@@ -487,7 +490,7 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
     explicit ArenaScope(PinnedArena *a) { g_arena = a; }
     ~ArenaScope() { g_arena = nullptr; }
   } arena_scope(&c->arena);
-  if (need & kNeedF32) need |= kNeedBvh | kNeedGrid;  // the binary32 images are derived from the binary64 ones
+  if (need & kNeedF32) need |= kNeedBvh | kNeedGrid;  // the binary32 images are derived from the binary64 ones (BVH2, grid)
   c->built = 0;
   c->have_scene = false;
   c->have_rtree = false;
@@ -601,7 +604,8 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
   c->build_info.bvh4_nodes = 0;
   c->build_info.bvh4_image_bytes = 0;
   c->build_info.bvh4_node_bytes = 0;
-  if (need & kNeedBvh) {
+  const bool want2 = (need & kNeedBvh) != 0, want4 = (need & kNeedBvh4) != 0 && ns == 0 && nm == 0 && nt > 0 && !c->knobs.no_bvh4;
+  if (want2 || want4) {
   if (c->builder == RTOW_BUILDER_DEVICE_LBVH) {
     // the tree is built in HBM from the record arrays just uploaded; the host only lays out
     // the image sections around it
@@ -610,6 +614,7 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
                                (const double *)c->tri.p, ns, nm, nt, s->camera.t0, s->camera.t1, s->camera.origin,
                                leaf_max, nullptr, &c->lbvh_scratch, &n_nodes);
     if (brc) return fail(RTOW_EHIP, "device BVH build failed (stage %d): %s", brc, hipGetErrorString(hipGetLastError()));
+    if (want2) {
     rtow::layout_scene_image(n_nodes, (size_t)(ns + nm + nt), sph, mov, tri, pmat, mats_bytes, img, true);
     if ((rc = c->blob.ensure(img.total_bytes))) return rc;
     // image sections: device-to-device copies of the arrays uploaded above, zeroed node section
@@ -623,10 +628,11 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
     brc = rtow::lbvh_emit(c->lbvh_scratch, leaf_max, bp, img.off_ids, n_nodes, nullptr);
     if (brc == 4) return fail(RTOW_EINVAL, "internal error: device-built scene image failed validation (BVH links)");
     if (brc) return fail(RTOW_EHIP, "device BVH emit failed (stage %d): %s", brc, hipGetErrorString(hipGetLastError()));
+    }
     // triangle meshes: the 4-wide image the BVH4 kernel walks, collapsed from the same radix tree ON THE DEVICE
     // (csrc/rtow_build.hip) — the reference builds its tree inside render()'s timer (src/render.cpp:73-110,141-188);
     // with the device builder nothing of the build runs on the host
-    if (ns == 0 && nm == 0 && nt > 0 && !c->knobs.no_bvh4 && leaf_max <= 4) {
+    if (want4 && leaf_max <= 4) {
       int n4 = 0, depth4 = 0;
       float rb[6];
       brc = rtow::lbvh_bvh4_collapse(c->lbvh_scratch, leaf_max, nullptr, &n4, &depth4, rb);
@@ -687,7 +693,8 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
     const double c_trav = c->knobs.bvh_ct >= 0.0 ? c->knobs.bvh_ct : (mesh_tree ? 1.5 : 0.0);
     rtow::build_bvh(sph, sph_r, mov, tri, bvh, leaf_max, c_trav, s->camera.t0, s->camera.t1);
     std::vector<int32_t> prim_order;  // the tree's primitive order before the leaf-order pass renumbers it (for the 4-wide image)
-    if (ns == 0 && nm == 0 && !c->knobs.no_bvh4 && leaf_max <= 4) prim_order = bvh.prim;
+    if (want4 && leaf_max <= 4) prim_order = bvh.prim;
+    if (want2) {
     if (ns == 0 && nm == 0 && !c->knobs.no_leaf_order) {
       // Triangle meshes: the image holds the triangle records and their material indices in LEAF order
       // and the id list is the identity, so a leaf test reads its records directly instead of id ->
@@ -708,16 +715,19 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
     if (!rtow::validate_scene_image(img, ns + nm + nt))
       return fail(RTOW_EINVAL, "internal error: scene image failed validation (BVH links)");
     if ((rc = upload(c->blob, img.blob))) return rc;
+    }
     // triangle meshes: the 4-wide tree collapsed from the same SAH tree (rtow_bvh4.h)
     c->have_bvh4 = false;
-    if (ns == 0 && nm == 0 && !c->knobs.no_bvh4) {
+    if (want4) {
       rtow::Bvh4Image img4;
       if (!prim_order.empty()) {  // the same SAH tree, collapsed (leaves of at most 4 triangles)
         bvh.prim = prim_order;
-        rtow::make_bvh4_image(bvh, tri, pmat, mats_bytes, s->camera.origin, img4);
         // an image that LDS cannot hold whole is read from L2 below the top of its tree: 64-byte nodes with
-        // binary16 planes (4 loads per node instead of 7; rtow_bvh4.h)
-        if (img4.ok && img4.blob.size() + bvh4_min_stack(c) * 4u * 1024u > kLdsLimit)
+        // binary16 planes (4 loads per node instead of 7; rtow_bvh4.h).  The records alone decide it for a big mesh
+        // (no point in building the binary32 image first: 20 ms of the 96.8k-triangle mesh's upload)
+        const bool surely_half = (size_t)nt * 100u + bvh4_min_stack(c) * 4u * 1024u > kLdsLimit;
+        rtow::make_bvh4_image(bvh, tri, pmat, mats_bytes, s->camera.origin, img4, /*half=*/surely_half);
+        if (!surely_half && img4.ok && img4.blob.size() + bvh4_min_stack(c) * 4u * 1024u > kLdsLimit)
           rtow::make_bvh4_image(bvh, tri, pmat, mats_bytes, s->camera.origin, img4, /*half=*/true);
       }
       if (img4.ok) {
@@ -1180,7 +1190,7 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
              : bvh4_ok ? RTOW_KERNEL_BVH4 : RTOW_KERNEL_BVH;
   if (kernel == RTOW_KERNEL_GRID && !c->have_grid) kernel = RTOW_KERNEL_BVH;  // scene not suited to a grid
   if (kernel == RTOW_KERNEL_BVH4 && !bvh4_ok) kernel = RTOW_KERNEL_BVH;
-  if (((kernel == RTOW_KERNEL_BVH || kernel == RTOW_KERNEL_BVH4) && !(c->built & kNeedBvh)) || (f32 && !(c->built & kNeedF32)))
+  if ((kernel == RTOW_KERNEL_BVH && !(c->built & kNeedBvh)) || (f32 && !(c->built & kNeedF32)))
     return fail(RTOW_ENOSCENE, "the resident scene was uploaded by rtow_render for another kernel / precision: "
                                "call rtow_scene_upload before rtow_render_device");
   if (kernel == RTOW_KERNEL_REFTREE) {
@@ -1544,6 +1554,7 @@ static int upload_for(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_
   const long long np = (long long)scene->n_spheres + scene->n_moving + scene->n_triangles;
   unsigned need;
   const int k = cfg->kernel;
+  const bool mesh = scene->n_spheres == 0 && scene->n_moving == 0 && scene->n_triangles > 0 && !c->knobs.no_bvh4;
   if (cfg->precision == RTOW_F32)
     need = kNeedAll;
   else if (k == RTOW_KERNEL_REFTREE || k == RTOW_KERNEL_BRUTE || (k == RTOW_KERNEL_AUTO && np <= 16))
@@ -1552,11 +1563,15 @@ static int upload_for(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_
     need = kNeedGrid;
   else if (k == RTOW_KERNEL_GRID)
     need = kNeedGrid | kNeedBvh;
+  else if (mesh && (k == RTOW_KERNEL_AUTO || k == RTOW_KERNEL_BVH4))
+    need = kNeedBvh4;  // the 4-wide image only (the binary image is another 20 ms and 10 MB for the 96.8k-triangle mesh)
   else
     need = kNeedBvh;
   rc = scene_upload(c, scene, need);
   if (rc == RTOW_OK && (need & kNeedGrid) && !(need & kNeedBvh) && !c->have_grid)
     rc = scene_upload(c, scene, need | kNeedBvh);  // the scene does not suit a grid: the walk falls back to the BVH
+  if (rc == RTOW_OK && need == kNeedBvh4 && !c->have_bvh4)
+    rc = scene_upload(c, scene, kNeedBvh);  // beyond the 4-wide format's limits: the binary walk takes the mesh
   return rc;
 }
 

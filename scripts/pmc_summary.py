@@ -35,6 +35,8 @@ d = {}
 if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
     # SQ_ACTIVE_INST_* count quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
     d["valu_issue_utilisation"] = round(g("SQ_ACTIVE_INST_VALU") * 4 / (g("GRBM_GUI_ACTIVE") / 8 * 1024), 4)
+if g("SQ_INSTS_VALU"):
+    d["valu_insts_per_launch"] = int(g("SQ_INSTS_VALU"))
 if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INSTS_VALU"):
     d["lane_activity"] = round(g("SQ_THREAD_CYCLES_VALU") / (g("SQ_INSTS_VALU") * 64), 4)
 if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
