@@ -189,7 +189,10 @@ __global__ void kg_fat_lists(const double *sph, const double *mov, int ns, unsig
   reinterpret_cast<uint32_t *>(dst)[3] = 0u;
   double *rec = reinterpret_cast<double *>(dst + 16);
   if (stride == 48u) {
-    for (int k = 0; k < 4; ++k) rec[k] = sph[(size_t)id * 4 + k];
+    const double *q = sph + (size_t)id * 4;
+    for (int k = 0; k < 4; ++k) rec[k] = q[k];
+    // k = |c|^2 - r^2 in the entry's padding (rtow_grid.h write_fat_entry: the same expression, no contraction)
+    reinterpret_cast<double *>(dst + 8)[0] = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) - fabs(q[3]);
   } else if ((int)id < ns) {
     const double *q = sph + (size_t)id * 4;
     rec[0] = q[0], rec[1] = q[1], rec[2] = q[2], rec[3] = 0.0, rec[4] = 0.0, rec[5] = 0.0, rec[6] = q[3], rec[7] = 0.0;

@@ -168,7 +168,13 @@ inline void write_fat_entry(unsigned char *dst, uint32_t stride, int32_t id, con
   std::memset(dst, 0, stride);
   std::memcpy(dst, &id, 4);
   if (stride == 48u) {
-    std::memcpy(dst + 16, &sph[(size_t)id * 4], 32);
+    // [id . k][cx cy][cz r2]: k = |c|^2 - r^2, the ray-independent part of the fast builds' discriminant (they test
+    // h = o.d - c.d, c' = |o|^2 - 2 c.o + k against a unit direction: 8 operations instead of 12; rtow_trace_bvh.h).
+    // The strict build reads c and r2 only.  (-ffp-contract=off on both builders: the images stay byte-identical.)
+    const double *q = &sph[(size_t)id * 4];
+    const double k = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) - std::fabs(q[3]);
+    std::memcpy(dst + 8, &k, 8);
+    std::memcpy(dst + 16, q, 32);
   } else if ((size_t)id < ns) {
     const double *q = &sph[(size_t)id * 4];
     const double rec[8] = {q[0], q[1], q[2], 0.0, 0.0, 0.0, q[3], 0.0};

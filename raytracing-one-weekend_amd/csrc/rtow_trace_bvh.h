@@ -26,7 +26,31 @@ struct Image {
     else
       return *reinterpret_cast<const uint32_t *>(g + off);
   }
+  __device__ __forceinline__ uint4 u4(uint32_t off) const {
+    if constexpr (LDS)
+      return *reinterpret_cast<const uint4 *>(rtow_lds + off);
+    else
+      return *reinterpret_cast<const uint4 *>(g + off);
+  }
+  __device__ __forceinline__ double d1(uint32_t off) const {
+    if constexpr (LDS)
+      return *reinterpret_cast<const double *>(rtow_lds + off);
+    else
+      return *reinterpret_cast<const double *>(g + off);
+  }
 };
+
+// Fast binary64 build, GRID walk: the walk runs on the UNIT direction (round 4).  With |d| = 1 the quadratic of a
+// sphere is t^2 + 2 h t + c = 0: no a in the discriminant, no 1/a in the roots; and with the ray-independent
+// k = |C|^2 - r^2 stored beside a cell-list sphere (rtow_grid.h) h = o.d - C.d and c = |o|^2 - 2 C.o + k take three fma
+// each from per-ray constants — 8 operations to the discriminant instead of 12, 2 less per resolved root.  The ray
+// parameter inside the walk is then a distance; the walk converts the closest hit back (t / |d|) when it returns, so
+// everything outside it keeps the reference's un-normalised rays (src/common-model.cpp:24-31 depends on |d|).
+// Rounding differs from the strict build's expressions at the 1e-12 level (cancellation in c), i.e. like any other
+// re-association of the fast build: parity by tolerance.  The strict build never takes this path.
+#if defined(RTOW_FAST_MATH) && !defined(RTOW_REAL_F32)
+#define RTOW_UNIT_RAYS 1
+#endif
 
 // An f32 upper bound of the closest hit so far, for the conservative f32 culling tests (boxes, grid cells).  Not the
 // correctly rounded-up conversion (no such instruction: __double2float_ru is a dozen instructions of integer
@@ -60,6 +84,12 @@ struct RayForms {
   real a, inv_a, time;
   V3d o64, d64;
   double a64, inv_a64, time64;
+  double tmin;  // RTOW_TMIN in the walk's ray parameter
+#ifdef RTOW_UNIT_RAYS
+  bool unit;    // d is a unit vector (a = 1): the fields below are set
+  double od, oo;  // o.d, |o|^2
+  V3d o2;         // -2 o
+#endif
 };
 __device__ __forceinline__ RayForms make_ray_forms(V3 o, V3 d, real time) {
   RayForms r;
@@ -78,8 +108,31 @@ __device__ __forceinline__ RayForms make_ray_forms(V3 o, V3 d, real time) {
   r.a64 = r.a;
   r.inv_a64 = r.inv_a;
 #endif
+  r.tmin = RTOW_TMIN;
+#ifdef RTOW_UNIT_RAYS
+  r.unit = false;
+  r.od = r.oo = 0.0;
+  r.o2 = V3d{0, 0, 0};
+#endif
   return r;
 }
+#ifdef RTOW_UNIT_RAYS
+// the forms of a ray whose direction `du` has been normalised; `len` = |d| of the original direction
+__device__ __forceinline__ RayForms make_unit_ray_forms(V3d o, V3d du, double time, double len) {
+  RayForms r;
+  r.o = r.o64 = o;
+  r.d = r.d64 = du;
+  r.time = r.time64 = time;
+  r.a = r.a64 = 1.0;
+  r.inv_a = r.inv_a64 = 1.0;
+  r.tmin = RTOW_TMIN * len;
+  r.unit = true;
+  r.od = dot(o, du);
+  r.oo = dot(o, o);
+  r.o2 = V3d{-2.0 * o.x, -2.0 * o.y, -2.0 * o.z};
+  return r;
+}
+#endif
 
 // Tests primitives ids[first .. first+count) of a scene image against the ray (the same code
 // as the STREAM kernel, so the accepted (t, primitive) is the same).  SMALL: the spheres are
@@ -92,6 +145,35 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
   if constexpr (SMALL) {
     if (off.fat != 0u) {  // wave-uniform: one round of LDS reads per entry instead of id -> record
       if (off.fat_stride == 48u) {
+#ifdef RTOW_UNIT_RAYS
+        if (ray.unit) {
+          for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t e = off.fat + 48u * (first + k);
+            uint4 hd = im.u4(e);  // id . k
+            double2 p0 = im.d2(e + 16u);
+            double cz = im.d1(e + 32u);
+            asm volatile("" : "+v"(hd.x), "+v"(hd.z), "+v"(hd.w), "+v"(p0.x), "+v"(p0.y), "+v"(cz));
+            const int id = (int)hd.x;
+            if (id == last_id) continue;
+            last_id = id;
+            ++nprim;
+            const double kk = __longlong_as_double((long long)(((unsigned long long)hd.w << 32) | hd.z));
+            const double h = __builtin_fma(-p0.x, ray.d64.x, __builtin_fma(-p0.y, ray.d64.y, __builtin_fma(-cz, ray.d64.z, ray.od)));
+            const double c = __builtin_fma(p0.x, ray.o2.x, __builtin_fma(p0.y, ray.o2.y, __builtin_fma(cz, ray.o2.z, ray.oo + kk)));
+            const double disc = __builtin_fma(h, h, -c);
+            if (disc >= 0.0) {
+              const double sq = fast_sqrt_pos(disc);  // (disc == 0: NaN roots, no hit — see sphere_resolve)
+              const double root1 = -h - sq, root2 = sq - h;
+              const double root = root1 >= ray.tmin ? root1 : root2;
+              if (root >= ray.tmin && root <= (double)best.t) {
+                best.t = (real)root;
+                best.prim = id;
+              }
+            }
+          }
+          return;
+        }
+#endif
         for (uint32_t k = 0; k < count; ++k) {
           const uint32_t e = off.fat + 48u * (first + k);
           const int id = (int)im.u32(e);
@@ -101,7 +183,7 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
           if (id == last_id) continue;
           last_id = id;
           ++nprim;
-          sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+          sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, ray.tmin, best);
         }
       } else {  // entries with motion: centre(time) = c0 + time * delta (src/oo-primitives.h:64-66; delta = 0 if static)
         for (uint32_t k = 0; k < count; ++k) {
@@ -116,7 +198,7 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
           const double cx = p0.x + ray.time64 * p1.y;
           const double cy = p0.y + ray.time64 * p2.x;
           const double cz = p1.x + ray.time64 * p2.y;
-          sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
+          sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, cx, cy, cz, p3.x, id, ray.tmin, best);
         }
       }
       return;
@@ -133,20 +215,20 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
 #ifdef RTOW_REAL_F32
       if constexpr (SMALL) {
         const float4 p = im.f4(off.sph32 + 16u * (uint32_t)id);
-        sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p.x, p.y, p.z, p.w, id, (float)RTOW_TMIN, best);
+        sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p.x, p.y, p.z, p.w, id, (float)ray.tmin, best);
         continue;
       }
 #endif
       const uint32_t r = off.sph + 32u * (uint32_t)id;
       const double2 p0 = im.d2(r), p1 = im.d2(r + 16u);
-      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, RTOW_TMIN, best);
+      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, p0.x, p0.y, p1.x, p1.y, id, ray.tmin, best);
     } else if (id < sc.n_sph + sc.n_mov) {
 #ifdef RTOW_REAL_F32
       if constexpr (SMALL) {
         const uint32_t r = off.mov32 + 32u * (uint32_t)(id - sc.n_sph);
         const float4 p0 = im.f4(r), p1 = im.f4(r + 16u);  // c0xyz dx | dy dz r2 -
         sphere_test<float>(ray.o, ray.d, ray.a, ray.inv_a, p0.x + ray.time * p0.w, p0.y + ray.time * p1.x,
-                           p0.z + ray.time * p1.y, p1.z, id, (float)RTOW_TMIN, best);
+                           p0.z + ray.time * p1.y, p1.z, id, (float)ray.tmin, best);
         continue;
       }
 #endif
@@ -155,19 +237,19 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
       const double cx = p0.x + ray.time64 * p1.y;
       const double cy = p0.y + ray.time64 * p2.x;
       const double cz = p1.x + ray.time64 * p2.y;
-      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, cx, cy, cz, p3.x, id, RTOW_TMIN, best);
+      sphere_test<double>(ray.o64, ray.d64, ray.a64, ray.inv_a64, cx, cy, cz, p3.x, id, ray.tmin, best);
     } else {
 #ifdef RTOW_REAL_F32
       const uint32_t r = off.tri + 48u * (uint32_t)(id - sc.n_sph - sc.n_mov);
       const float4 q0 = im.f4(r), q1 = im.f4(r + 16u), q2 = im.f4(r + 32u);  // A e1 | e1 e2 | e2 n
       triangle_test<float>(ray.o, ray.d, V3{q0.x, q0.y, q0.z}, V3{q0.w, q1.x, q1.y}, V3{q1.z, q1.w, q2.x},
-                           V3{q2.y, q2.z, q2.w}, id, (float)RTOW_TMIN, best);
+                           V3{q2.y, q2.z, q2.w}, id, (float)ray.tmin, best);
 #else
       const uint32_t r = off.tri + 96u * (uint32_t)(id - sc.n_sph - sc.n_mov);
       const double2 q0 = im.d2(r), q1 = im.d2(r + 16u), q2 = im.d2(r + 32u), q3 = im.d2(r + 48u),
                     q4 = im.d2(r + 64u), q5 = im.d2(r + 80u);
       triangle_test<double>(ray.o64, ray.d64, V3d{q0.x, q0.y, q1.x}, V3d{q1.y, q2.x, q2.y}, V3d{q3.x, q3.y, q4.x},
-                            V3d{q4.y, q5.x, q5.y}, id, RTOW_TMIN, best);
+                            V3d{q4.y, q5.x, q5.y}, id, ray.tmin, best);
 #endif
     }
   }

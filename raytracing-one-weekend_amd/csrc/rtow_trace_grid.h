@@ -31,7 +31,21 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
     best.t = (real)__builtin_huge_val();
     best.prim = -1;
   }
+#ifdef RTOW_UNIT_RAYS
+  // the walk runs on the unit direction (rtow_trace_bvh.h, RTOW_UNIT_RAYS): its ray parameter is a distance.  The
+  // closest hit goes out in the caller's parameter, t = distance / |d|, ONCE: when the segment's walk is complete.  A
+  // walk that stops to be resumed keeps `best.t` as the distance it is (the caller does not read it before the walk
+  // is complete): converting there and back on every resume would round it differently for every schedule of the
+  // wave, and the image must not depend on who traces what next to whom.
+  const double a_ref = dot(d, d);
+  const double inv_len = fast_rsqrt(a_ref), len = a_ref * inv_len;
+  d = d * inv_len;
+  const RayForms ray = make_unit_ray_forms(o, d, time, len);
+  const float tmin32w = 0.0009f * (float)len;
+#else
   const RayForms ray = make_ray_forms(o, d, time);
+  const float tmin32w = 0.0009f;
+#endif
   ImgOffsets off = {sc.g_off_ids, sc.g_off_sph, sc.g_off_mov, sc.g_off_tri, 0u, 0u, sc.g_off_sph32, sc.g_off_mov32};
   int last_id = -1;
   // header: wave-uniform scalar loads from the global copy of the image
@@ -65,7 +79,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         }
         nprim += 4u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sphere_resolve<double>(dd[j], hh[j], ray.a64, ray.inv_a64, id[j], RTOW_TMIN, best);
+        for (int j = 0; j < 4; ++j) sphere_resolve<double>(dd[j], hh[j], ray.a64, ray.inv_a64, id[j], ray.tmin, best);
         last_id = id[3];
       } else {
         leaf_test<LDS, false>(im, sc, off, lf + k, 4u, ray, best, nprim, last_id);
@@ -80,8 +94,8 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         const double da = sphere_disc<double>(ray.o64, ray.d64, ray.a64, a0.x, a0.y, a1.x, a1.y, ha);
         const double db = sphere_disc<double>(ray.o64, ray.d64, ray.a64, b0.x, b0.y, b1.x, b1.y, hb);
         nprim += 2u;
-        sphere_resolve<double>(da, ha, ray.a64, ray.inv_a64, ia, RTOW_TMIN, best);
-        sphere_resolve<double>(db, hb, ray.a64, ray.inv_a64, ib, RTOW_TMIN, best);
+        sphere_resolve<double>(da, ha, ray.a64, ray.inv_a64, ia, ray.tmin, best);
+        sphere_resolve<double>(db, hb, ray.a64, ray.inv_a64, ib, ray.tmin, best);
         last_id = ib;
       } else {
         leaf_test<LDS, false>(im, sc, off, lf + k, 2u, ray, best, nprim, last_id);
@@ -100,7 +114,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
   const float ax = fmaf(gx, ix, -oix), bx = fmaf(hx, ix, -oix);
   const float ay = fmaf(gy, iy, -oiy), by = fmaf(hy, iy, -oiy);
   const float az = fmaf(gz, iz, -oiz), bz = fmaf(hz, iz, -oiz);
-  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), fmaxf(0.0009f, t_resume * 0.999999f)));
+  const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), fmaxf(tmin32w, t_resume * 0.999999f)));
   const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax32));
   bool walking = active && t0 <= t1 * 1.00002f;
 
@@ -184,12 +198,18 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
       if (suspend) {
         // a lane whose next cell starts beyond the hit it has just found is finished after all
         t_resume = (walking && !(t_entry > tmax32)) ? t_entry : 0.0f;
+#ifdef RTOW_UNIT_RAYS
+        if (!(t_resume > 0.0f)) best.t = best.t * inv_len;  // (the lanes whose walk is complete)
+#endif
         return best;
       }
       if (!any_walking && !__any(q0 != 0u)) break;
     }
   }
   t_resume = 0.0f;
+#ifdef RTOW_UNIT_RAYS
+  best.t = best.t * inv_len;
+#endif
   return best;
 }
 

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(1024) RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)(cons
     const bool walking = phase == PH_WALK;
     if (__ballot(walking) != 0ull) {
       if constexpr (STAMPS) stamps.iters += 1;
-      if (walking) bvh4_step<FULL>(im, P, ray, tmax32, stk, lane_g, cur, sa, q0, q1, nnode);
+      if (walking) bvh4_step<FULL, false>(im, P, ray, tmax32, stk, lane_g, cur, sa, q0, q1, nnode);
       stamps.mark(RG_WALK);
       // Leaf phase: when enough lanes hold a queued leaf, or when no lane can take a step (every
       // walking lane either has nothing in hand or holds a leaf it cannot queue).
