@@ -433,10 +433,9 @@ static int multi_render(rtow_multi *m, const rtow_config_t *cfg, void *host_out,
                                                 (uint32_t)H, (uint32_t)cfg->tile_rows, r0.stream);
         if (lrc != 0) e = (hipError_t)lrc;
       }
-      if (e == hipSuccess) e = hipMemcpyAsync(host_out, m->d_image, image_bytes, hipMemcpyDeviceToHost, r0.stream);
-      if (e != hipSuccess) rc = rtow::set_last_error(RTOW_EHIP, "%s: placement / copy on device %d: %s", what, r0.device, hipGetErrorString(e));
+      if (e != hipSuccess) rc = rtow::set_last_error(RTOW_EHIP, "%s: placement on device %d: %s", what, r0.device, hipGetErrorString(e));
     }
-    // wait for every stream (the first device's copy is the last thing queued)
+    // wait for every stream (the first device's placement kernel is the last thing queued)
     for (int r = 0; r < n; ++r) {
       Rank &me = m->ranks[(size_t)r];
       (void)hipSetDevice(me.device);
@@ -445,6 +444,14 @@ static int multi_render(rtow_multi *m, const rtow_config_t *cfg, void *host_out,
         rc = rtow::set_last_error(RTOW_EHIP, "rank %d (device %d): hipStreamSynchronize: %s", r, me.device, hipGetErrorString(e));
     }
     if (rc != RTOW_OK) return rc;
+    {
+      // the ONE device-to-host copy, straight into the caller's (pageable) buffer: the runtime's own blocking copy —
+      // what rtow_render / rtow_render_rgb8 use; the asynchronous form into pageable memory measured 0.25 ms slower per
+      // frame, a pinned landing buffer plus a host pass slower still (rtow_capi.cpp)
+      (void)hipSetDevice(m->ranks[0].device);
+      const hipError_t e = hipMemcpy(host_out, m->d_image, image_bytes, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) return rtow::set_last_error(RTOW_EHIP, "%s: copy of the frame from device %d: %s", what, m->ranks[0].device, hipGetErrorString(e));
+    }
     for (int r = 0; r < n; ++r) {  // never RTOW_OK with samples dropped (the end-of-launch bound of the trace kernel)
       (void)hipSetDevice(m->ranks[(size_t)r].device);
       if ((rc = rtow::ctx_check_dropped(m->ranks[(size_t)r].ctx))) return rc;
