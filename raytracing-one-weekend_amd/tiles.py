@@ -33,12 +33,19 @@ class StripGather:
         self.local = torch.zeros((self.max_rows, width, 3), dtype=torch.float64, device=device)
         self.image = None
         self.parts = None
-        self.index = None
+        self.gathered = None
+        self.source_row = None
         if rank == dst:
             self.image = torch.zeros((height, width, 3), dtype=torch.float64, device=device)
-            self.parts = [torch.empty_like(self.local) for _ in range(world)]
-            self.index = [torch.tensor(strip_rows(height, tile_rows, world, r), dtype=torch.long, device=device)
-                          for r in range(world)]
+            # ONE buffer [rank][max_rows][W][3] (the gather's output list is views of it) and, for every global row,
+            # where it sits in that buffer: rank (i // tile_rows) % world, local row (i // tile_rows // world) * tile_rows
+            # + i % tile_rows — so the strips go back to their rows with ONE index_select (round 4; it was one
+            # index_copy_ launch per rank)
+            self.gathered = torch.empty((world, self.max_rows, width, 3), dtype=torch.float64, device=device)
+            self.parts = [self.gathered[r] for r in range(world)]
+            src = [((i // tile_rows) % world) * self.max_rows + (i // tile_rows // world) * tile_rows + i % tile_rows
+                   for i in range(height)]
+            self.source_row = torch.tensor(src, dtype=torch.long, device=device)
 
     def gather(self):
         """local strips -> full image on rank dst (returns it there, None elsewhere)."""
@@ -49,10 +56,7 @@ class StripGather:
         dist.gather(self.local, self.parts if self.rank == self.dst else None, dst=self.dst)
         if self.rank != self.dst:
             return None
-        for r in range(self.world):
-            n = self.index[r].numel()
-            if n:
-                self.image.index_copy_(0, self.index[r], self.parts[r][:n])
+        torch.index_select(self.gathered.view(self.world * self.max_rows, self.w, 3), 0, self.source_row, out=self.image)
         return self.image
 
 

@@ -272,3 +272,41 @@ def test_product_reference_tree_builder_matches_the_oracles_tree(which):
     if survey is not None:
         assert float("%.6g" % vol.value) == survey
     assert 0 <= depth.value < 48
+
+
+def test_round4_bench_line_carries_the_blocks_the_review_asked_for():
+    """profiles/r04_bench_driver_style.json (the driver's command on the final sources of round 4): the contract's
+    fields, the roofline object as the BINDING bound with the metric's equivalent-streaming figure beside it, the
+    per-rank projection of configs[2] at N = 2 / 4 / 8, the multi-device handle's per-frame cost, and what a caller
+    waits for on the meshes with either builder."""
+    import json
+
+    base = json.loads((REPO / "BASELINE.json").read_text())
+    line = json.loads((REPO / "profiles" / "r04_bench_driver_style.json").read_text())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "scale_projection", "multi_handle",
+                "value_e2e", "scaling_base", "other_configs"):
+        assert key in line, key
+    assert line["metric"] == base["metric"] and line["dtype"] == "f64" and line["n_gpus"] == 1 and line["vs_baseline"] is None
+    assert "1200x800, 100 spp, 50 bounces" in line["config"]["workload"]
+    samples = 1200 * 800 * line["config"]["spp_effective"]
+    assert abs(line["value"] - samples / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
+    r = line["roofline"]
+    assert r["bound"] == "valu_issue" and r["pmc_stale"] is False and r["kernel_ms"] <= line["ms_per_step"]
+    assert abs(r["frac"] - min(r["issue_utilisation"], 1.0) * r["lane_activity"]) < 1e-3 and 0.3 < r["frac"] < 0.7
+    assert r["traffic"] > 2e8  # HBM bytes per launch (PMC): the partial sums
+    h = r["hbm_equivalent_streaming"]
+    assert h["bound"] == "hbm" and h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-4
+    sp = line["scale_projection"]["by_n"]
+    assert [b["n_gpus"] for b in sp] == [2, 4, 8] and [b["tile_rows"] for b in sp] == [8, 8, 4]
+    for b in sp:
+        assert len(b["per_rank"]) == b["n_gpus"] and b["kernel_ms_max"] >= b["kernel_ms_mean"] > 0
+        assert abs(b["projected_Msamples_per_s"] - 1200 * 800 * 500 / (b["step_ms_max"] * 1e-3) / 1e6) / b["projected_Msamples_per_s"] < 1e-3
+        assert 0.5 < b["projected_efficiency"] <= 1.02
+    m = line["multi_handle"]
+    assert m["use_rccl"] is True and 0.9 < m["rgb8"]["over_rtow_render_rgb8"] < 1.1
+    meshes = [o for o in line["other_configs"] if "end_to_end_rgb8" in o]
+    assert len(meshes) == 2 and all({"host_sah", "device_lbvh"} <= set(o["end_to_end_rgb8"]) for o in meshes)
+    assert all(o["end_to_end_rgb8"]["device_lbvh"]["bvh4_nodes"] > 0 for o in meshes)  # the device builder makes the 4-wide image
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "Msamples/s"
