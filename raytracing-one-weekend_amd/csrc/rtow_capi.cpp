@@ -262,6 +262,7 @@ struct Knobs {
                                   //   pixel, like the strict build).  5 / 10 / 20 / 25: 10.88 / 11.18 / 10.22 / 9.55 Gsamples/s on C2
   int sched_chunk_mesh = 16;      //   ... for a scene of triangles only (its walks are longer and resumable: fewer, longer items;
                                   //   4 / 8 / 16 / 32 samples: 4.60 / 4.64 / 4.69 / 4.68 Gsamples/s on C4, 2.29 / 2.30 / 2.32 / 2.32 on C5)
+  bool no_spec = false;           // RTOW_NO_SPEC: always the generic GRID kernel (A/B against the scene-class specialisations)
   int tail_bound = 0;             // RTOW_TAIL_BOUND (tests only): trips of the end-of-launch protocol before a wave gives up
                                   //   its samples (0 = the structural bound); a small value forces the RTOW_EHIP path
   void read() {
@@ -307,6 +308,7 @@ struct Knobs {
     sched_chunk = std::min(std::max(geti("RTOW_SCHED_CHUNK", 10), 0), 4096);
     sched_chunk_mesh = std::min(std::max(geti("RTOW_SCHED_CHUNK_MESH", 16), 0), 4096);
     tail_bound = std::max(geti("RTOW_TAIL_BOUND", 0), 0);
+    no_spec = std::getenv("RTOW_NO_SPEC") != nullptr;
   }
 };
 
@@ -333,6 +335,7 @@ struct rtow_ctx {
   DevBuf blob32, gblob32, cam32_dev;  // the f32 build's scene images and camera
   rtow::DevScene ds32{};               // ds with the f32 images' pointers and offsets
   uint32_t gblob_bytes = 0;
+  uint32_t grid_fat_stride = 0;  // bytes per fat cell-list entry of the resident grid image (0: plain id lists)
   bool have_grid = false;
   uint32_t blob_bytes = 0;
   long long bvh_nodes = 0;
@@ -813,6 +816,7 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
   }
   const double t_grid1 = now_ms();
   c->have_grid = gimg.ok;
+  c->grid_fat_stride = (gimg.ok && gimg.off_fat) ? gimg.fat_stride : 0u;
   c->gblob_bytes = 0;
   if (gimg.ok) {
     if (!grid_on_device && (rc = upload(c->gblob, gimg.blob))) return rc;
@@ -1368,6 +1372,13 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
   P.partials = (double *)c->partials.p;
   P.stack = (uint32_t *)c->stack.p;
   P.spill = (uint32_t *)c->spill.p;
+  // scene-class specialisation of the GRID kernel (rtow_device.h): static spheres with 48-byte fat lists, or static +
+  // moving spheres with 80-byte ones, image in LDS, binary64 builds
+  P.spec = rtow::kSpecGeneric;
+  if (kernel == RTOW_KERNEL_GRID && lds_bytes > 0 && !f32 && !c->knobs.no_spec && scene.n_tri == 0) {
+    if (scene.n_mov == 0 && c->grid_fat_stride == 48u) P.spec = rtow::kSpecStaticSpheres;
+    if (scene.n_mov > 0 && c->grid_fat_stride == 80u) P.spec = rtow::kSpecMovingSpheres;
+  }
   P.b4_trips = c->knobs.bvh4_sm ? 0u : 1u;
   {
     const bool b4 = kernel == RTOW_KERNEL_BVH4;

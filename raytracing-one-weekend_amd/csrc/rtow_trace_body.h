@@ -296,7 +296,8 @@ __device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, in
 
 // KERNEL: 1 = STREAM, 2 = BVH, 3 = GRID, 4 = BVH4;  LDS: scene image staged in LDS (2 and 3; the
 // BVH4 kernel always uses LDS: the image or its top, and the traversal stack)
-template <int KERNEL, bool LDS, bool STAMPS = false>
+// SPEC: scene-class specialisation (GRID kernel only; rtow_device.h kSpec*)
+template <int KERNEL, bool LDS, bool STAMPS = false, int SPEC = 0>
 __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     RTOW_CAT(rtow_trace_, RTOW_SUFFIX)(const TraceParams P) {
   const DevScene &sc = P.sc;
@@ -633,6 +634,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         const uint32_t o_tri = KERNEL == 3 ? sc.g_off_tri : sc.off_tri;
         const uint32_t o_pmat = KERNEL == 3 ? sc.g_off_pmat : sc.off_pmat;
         const uint32_t o_mats = KERNEL == 3 ? sc.g_off_mats : sc.off_mats;
+        if constexpr (SPEC == 1) __builtin_assume(pid < sc.n_sph);
+        if constexpr (SPEC == 2) __builtin_assume(pid < sc.n_sph + sc.n_mov);
         if (pid < sc.n_sph + sc.n_mov) {
           V3 center;
           bool inward;  // negative radius: only the sign of the signed r*r is used here
@@ -866,7 +869,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
                                            P.walk_cap, P.walk_max_open);
     } else if constexpr (KERNEL == 3) {
       if constexpr (STAMPS) stamps.primary = __ballot(tracing && depth == P.max_child_rays);
-      best = closest_hit_grid<LDS, STAMPS>(im, sc, ro, rd, rtime, tracing, nnode, nprim, stamps, best, t_resume, P.walk_cap,
+      best = closest_hit_grid<LDS, STAMPS, SPEC>(im, sc, ro, rd, rtime, tracing, nnode, nprim, stamps, best, t_resume, P.walk_cap,
                                            P.walk_max_open, P.leaf_votes);
     } else if constexpr (KERNEL == 2) {
       // the walk uses wave votes, so every lane of the wave enters it
@@ -1020,9 +1023,9 @@ static int launch_sm4(const TraceParams &p, int grid, int block, unsigned lds_by
 }
 
 // kernel: 1 STREAM, 2 BVH, 3 GRID, 4 BVH4; +16 = diagnostic region stamps (LDS variants only)
-template <int K, bool L, bool S>
+template <int K, bool L, bool S, int SPEC = 0>
 static int launch_one(const TraceParams &p, int grid, int block, unsigned lds_bytes, hipStream_t st) {
-  auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<K, L, S>;
+  auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<K, L, S, SPEC>;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1040,8 +1043,11 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
     case 1: return launch_one<1, false, false>(p, grid, block, 0, st);
     case 2: return lds ? launch_one<2, true, false>(p, grid, block, lds_bytes, st)
                        : launch_one<2, false, false>(p, grid, block, 0, st);
-    case 3: return lds ? launch_one<3, true, false>(p, grid, block, lds_bytes, st)
-                       : launch_one<3, false, false>(p, grid, block, 0, st);
+    case 3:
+      if (lds && p.spec == kSpecStaticSpheres) return launch_one<3, true, false, 1>(p, grid, block, lds_bytes, st);
+      if (lds && p.spec == kSpecMovingSpheres) return launch_one<3, true, false, 2>(p, grid, block, lds_bytes, st);
+      return lds ? launch_one<3, true, false>(p, grid, block, lds_bytes, st)
+                 : launch_one<3, false, false>(p, grid, block, 0, st);
     case 4:
     case 4 + 16: {
       const bool full = p.sc.b4_half == 0u, stamps = kernel == 4 + 16;  // (binary32 nodes <=> staged whole)

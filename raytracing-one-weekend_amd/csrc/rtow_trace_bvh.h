@@ -137,12 +137,16 @@ __device__ __forceinline__ RayForms make_unit_ray_forms(V3d o, V3d du, double ti
 // Tests primitives ids[first .. first+count) of a scene image against the ray (the same code
 // as the STREAM kernel, so the accepted (t, primitive) is the same).  SMALL: the spheres are
 // grid-cell members, tested in binary32 by the f32 build (no effect in the binary64 builds).
-template <bool LDS, bool SMALL>
+// SPEC (rtow_device.h, kSpec*): what the host knows about the scene — the classes that cannot occur and the list
+// format that is there are told to the compiler, which drops their code (and the registers it would hold).
+template <bool LDS, bool SMALL, int SPEC = 0>
 __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &sc, ImgOffsets off,
                                           uint32_t first, uint32_t count, const RayForms &ray, Closest &best,
                                           uint32_t &nprim, int &last_id) {
 #ifndef RTOW_REAL_F32
   if constexpr (SMALL) {
+    if constexpr (SPEC == 1) __builtin_assume(off.fat != 0u && off.fat_stride == 48u);
+    if constexpr (SPEC == 2) __builtin_assume(off.fat != 0u && off.fat_stride == 80u);
     if (off.fat != 0u) {  // wave-uniform: one round of LDS reads per entry instead of id -> record
       if (off.fat_stride == 48u) {
 #ifdef RTOW_UNIT_RAYS
@@ -207,6 +211,8 @@ __device__ __forceinline__ void leaf_test(const Image<LDS> &im, const DevScene &
 #endif
   for (uint32_t k = 0; k < count; ++k) {
     const int id = (!SMALL && sc.leaf_direct) ? (int)(first + k) : (int)im.u32(off.ids + 4u * (first + k));
+    if constexpr (SPEC == 1) __builtin_assume(id < sc.n_sph);
+    if constexpr (SPEC == 2) __builtin_assume(id < sc.n_sph + sc.n_mov);
     // one-entry mailbox: a primitive spanning adjacent grid cells is listed in each of them
     if (id == last_id) continue;
     last_id = id;

@@ -19,7 +19,7 @@
 // point or its predecessor, so no cell is skipped; a cell tested twice changes nothing).  Because of that
 // step back, `cap` must be at least 3 (the host clamps it): at most two consecutive cell crossings share one
 // ray parameter, so three steps always end in a cell that starts later than the one the lane resumed in.
-template <bool LDS, bool ST>
+template <bool LDS, bool ST, int SPEC = 0>
 __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const DevScene &sc, V3 o,
                                                     V3 d, real time, bool active, uint32_t &nnode,
                                                     uint32_t &nprim, Stamps<ST> &stamps, Closest best,
@@ -69,7 +69,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
       int id[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) id[j] = (int)im.u32(off.ids + 4u * (lf + k + j));
-      if (id[0] < sc.n_sph && id[1] < sc.n_sph && id[2] < sc.n_sph && id[3] < sc.n_sph) {
+      if (SPEC == 1 || (id[0] < sc.n_sph && id[1] < sc.n_sph && id[2] < sc.n_sph && id[3] < sc.n_sph)) {
         double dd[4], hh[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -82,12 +82,12 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         for (int j = 0; j < 4; ++j) sphere_resolve<double>(dd[j], hh[j], ray.a64, ray.inv_a64, id[j], ray.tmin, best);
         last_id = id[3];
       } else {
-        leaf_test<LDS, false>(im, sc, off, lf + k, 4u, ray, best, nprim, last_id);
+        leaf_test<LDS, false, SPEC>(im, sc, off, lf + k, 4u, ray, best, nprim, last_id);
       }
     }
     for (; k + 1 < n_large; k += 2) {
       const int ia = (int)im.u32(off.ids + 4u * (lf + k)), ib = (int)im.u32(off.ids + 4u * (lf + k + 1));
-      if (ia < sc.n_sph && ib < sc.n_sph) {
+      if (SPEC == 1 || (ia < sc.n_sph && ib < sc.n_sph)) {
         const uint32_t ra = off.sph + 32u * (uint32_t)ia, rb = off.sph + 32u * (uint32_t)ib;
         const double2 a0 = im.d2(ra), a1 = im.d2(ra + 16u), b0 = im.d2(rb), b1 = im.d2(rb + 16u);
         double ha, hb;
@@ -98,10 +98,10 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         sphere_resolve<double>(db, hb, ray.a64, ray.inv_a64, ib, ray.tmin, best);
         last_id = ib;
       } else {
-        leaf_test<LDS, false>(im, sc, off, lf + k, 2u, ray, best, nprim, last_id);
+        leaf_test<LDS, false, SPEC>(im, sc, off, lf + k, 2u, ray, best, nprim, last_id);
       }
     }
-    if (k < n_large) leaf_test<LDS, false>(im, sc, off, lf + k, n_large - k, ray, best, nprim, last_id);
+    if (k < n_large) leaf_test<LDS, false, SPEC>(im, sc, off, lf + k, n_large - k, ray, best, nprim, last_id);
   }
   float tmax32 = round_up_f32(best.t);
 
@@ -186,11 +186,11 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         stamps.leaf_lanes += (unsigned long long)__popcll(m_pending);
         if (m_pending != 0ull && (m_pending & ~stamps.primary) == 0ull) stamps.phases_cam += 1;
       }
-      if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
+      if (q0 != 0u) leaf_test<LDS, true, SPEC>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
       q0 = q1;
       q1 = 0u;
       if (suspend && __any(q0 != 0u)) {  // both queued cells before stopping
-        if (q0 != 0u) leaf_test<LDS, true>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
+        if (q0 != 0u) leaf_test<LDS, true, SPEC>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
         q0 = 0u;
       }
       tmax32 = round_up_f32(best.t);
