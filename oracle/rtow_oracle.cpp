@@ -174,8 +174,9 @@ inline void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 //   first block of a sample : u, v, time = top 21 bits of w0, w1, w2 (* 2^-21); first lens-disk
 //                             candidate = w3 and the 11+11+10 low bits of w0..w2 (* 2^-32 each)
 //   further lens-disk block : two candidates (w0, w1), (w2, w3), 32 bits per coordinate
-//   first block of a bounce : ONE unit-ball candidate from (w0, w1) — x, y = top 21 bits, z = the
-//                             11+10 low bits left over — and the dielectric coin w2 * 2^-32
+//   first block of a bounce : a unit-ball candidate from (w0, w1) — x, y = top 21 bits, z = the
+//                             11+10 low bits left over — and EITHER the dielectric coin w2 * 2^-32 (a bounce that
+//                             draws one) OR a second candidate from (w2, w3) (every other bounce; round 4)
 //   further scatter block   : two unit-ball candidates, (w0, w1) and (w2, w3)
 struct PhiloxDraw {
   uint64_t seed = 0;
@@ -261,12 +262,22 @@ struct PhiloxDraw {
     pos = 0;
     coin_peeked = true;
   }
+  // The first block of a bounce: candidate #1 from words (0, 1); words (2, 3) are the dielectric coin (word 2) when the
+  // bounce drew one, and otherwise candidate #2 (round 4: a bounce without a coin — Lambertian, Metal, total
+  // reflection — finds two candidates in its first block).  Every further block: two candidates, (0, 1) and (2, 3).
+  bool first_has_second = false;
   void request_scatter() {
     if (scat_k == 0) {
       uint32_t o[4];
       block(r++, o);
       ball_from_pair(o[0], o[1], buf);
-    } else if (scat_k & 1) {
+      first_has_second = !coin_peeked;
+      if (first_has_second) ball_from_pair(o[2], o[3], stash_scat);
+    } else if (scat_k == 1 && first_has_second) {
+      buf[0] = stash_scat[0];
+      buf[1] = stash_scat[1];
+      buf[2] = stash_scat[2];
+    } else if (((scat_k - (first_has_second ? 2 : 1)) & 1) == 0) {  // the first candidate of a further block
       uint32_t o[4];
       block(r++, o);
       ball_from_pair(o[0], o[1], buf);
@@ -1114,16 +1125,17 @@ double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32
     g.request_disk();
     return k < 2 ? g.buf[k] : g.stash_disk[k - 2];
   }
-  if (kind == 2) {  // first unit-ball block of a bounce: k = 0..2 candidate, 3 the coin
-    if (k == 3) {
+  if (kind == 2) {  // first unit-ball block of a bounce: k = 0..2 candidate, 3 the coin, 4..6 the second candidate of a
+    if (k == 3) {   // bounce without a coin
       g.request_coin();
       return g.buf[0];
     }
     g.request_scatter();
-    return g.buf[k];
+    return k < 3 ? g.buf[k] : g.stash_scat[k - 4];
   }
   // kind 3: a later unit-ball block: k = 0..2 first candidate, 3..5 second candidate
   g.scat_k = 1;
+  g.first_has_second = false;
   g.request_scatter();
   return k < 3 ? g.buf[k] : g.stash_scat[k - 3];
 }

@@ -256,7 +256,9 @@ __device__ __forceinline__ void camera_ray(const TraceParams &P, Rng &g, uint32_
 __device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, int kind, real m_fuzz, real m_ir, V3 rd,
                                             V3 normal, bool front, V3 &dir) {
   real coin;
-  V3 rnd = rng_scatter(g, k0, k1, coin);
+  BallCand c1, c2;
+  rng_scatter_first(g, k0, k1, coin, c1, c2);
+  bool used_coin = false;
   V3 dirbase = {0, 0, 0};
   if (kind == 2) {
     const real ir = m_ir;
@@ -266,6 +268,7 @@ __device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, in
     const real ratio = front ? fast_rcp(ir) : ir;
     bool refl = ratio * sin_theta > real(1.0);
     if (!refl) {
+      used_coin = true;
       real r0 = fast_div(real(1.0) - ratio, real(1.0) + ratio);
       r0 = r0 * r0;
       const real x = real(1.0) - cos_theta;
@@ -277,12 +280,16 @@ __device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, in
   } else if (kind == 1) {
     dirbase = reflect(rd, normal);
   }
-  // random_unit_vector(): reject candidates outside the unit ball (random-utils.cpp:23-33)
-  while (dot(rnd, rnd) >= real(1.0)) {  // two candidates per further block
-    V3 ca, cb;
-    rng_scatter2(g, k0, k1, ca, cb);
-    rnd = dot(ca, ca) >= real(1.0) ? cb : ca;
+  // random_unit_vector(): reject candidates outside the unit ball (random-utils.cpp:23-33).  The first block holds
+  // a second candidate when the bounce drew no coin; every further block two.  (Exact integer test, rtow_trace_rng.h.)
+  BallCand cand = c1;
+  if (ball_outside(cand) && !used_coin) cand = c2;
+  while (ball_outside(cand)) {
+    BallCand ca, cb;
+    rng_scatter2i(g, k0, k1, ca, cb);
+    cand = ball_outside(ca) ? cb : ca;
   }
+  const V3 rnd = ball_point(cand);
   bool absorbed = false;
   if (kind == 0) {
     absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
@@ -738,6 +745,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       // the first unit-ball candidate of the bounce comes with the dielectric coin (word 2)
       const real coin = (real)o2 * real(0x1p-32);
       cand = ball_ints(o0, o1);
+      bool used_coin = false;  // src/common-model.cpp:53-54: the coin is drawn only if refraction is possible
       if (kind == 2) {
         const real ir = m_ir;
         const V3 unit = normalize(rd);
@@ -746,6 +754,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         const real ratio = front ? fast_rcp(ir) : ir;
         bool refl = ratio * sin_theta > real(1.0);
         if (!refl) {
+          used_coin = true;
           real r0 = fast_div(real(1.0) - ratio, real(1.0) + ratio);
           r0 = r0 * r0;
           const real x = real(1.0) - cos_theta;
@@ -758,6 +767,13 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         dirbase = reflect(rd, normal);
       }
       rej = ball_outside(cand);
+      // a bounce that drew no coin (Lambertian, Metal, total reflection) finds a SECOND candidate in words 2, 3 of its
+      // first block (round 4; oracle/rtow_oracle.cpp PhiloxDraw::request_scatter): half a rejection round less per
+      // trip for ten instructions
+      if (rej && !used_coin) {
+        cand = ball_ints(o2, o3);
+        rej = ball_outside(cand);
+      }
     }
     // rejection sampling (random-utils.cpp:23-41): every further block carries two candidates
     uint32_t rej_trips = 0u;  // (diagnostic build only)

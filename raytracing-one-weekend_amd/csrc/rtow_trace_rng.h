@@ -92,17 +92,20 @@ __device__ __forceinline__ V3 ball_point(BallCand c) {
   return V3{(real)c.x * s21, (real)c.y * s21, (real)c.z * s21};
 }
 __device__ __forceinline__ V3 ball_from_pair(uint32_t lo, uint32_t hi) { return ball_point(ball_ints(lo, hi)); }
-__device__ __forceinline__ V3 rng_scatter(Rng &g, uint32_t k0, uint32_t k1, real &coin) {
+// first block of a bounce: candidate (w0, w1), the coin (w2) and — for a bounce that does not use the coin — a second
+// candidate (w2, w3)
+__device__ __forceinline__ void rng_scatter_first(Rng &g, uint32_t k0, uint32_t k1, real &coin, BallCand &a, BallCand &b) {
   uint32_t o0, o1, o2, o3;
   philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
   coin = (real)o2 * real(0x1p-32);
-  return ball_from_pair(o0, o1);
+  a = ball_ints(o0, o1);
+  b = ball_ints(o2, o3);
 }
-__device__ __forceinline__ void rng_scatter2(Rng &g, uint32_t k0, uint32_t k1, V3 &a, V3 &b) {
+__device__ __forceinline__ void rng_scatter2i(Rng &g, uint32_t k0, uint32_t k1, BallCand &a, BallCand &b) {
   uint32_t o0, o1, o2, o3;
   philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
   g.r += 1u;
-  a = ball_from_pair(o0, o1);
-  b = ball_from_pair(o2, o3);
+  a = ball_ints(o0, o1);
+  b = ball_ints(o2, o3);
 }

@@ -28,7 +28,7 @@ CLASSES = ['mov', 'sel', 'cmp', 'f64', 'f32', 'int', 'lds', 'vmem', 'salu', 'wai
 
 def main():
     path = sys.argv[1]
-    kern = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('--') else 'rtow_trace_fastILi3ELb1ELb0'
+    kern = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith('--') else 'rtow_trace_fastILi3ELb1ELb0ELi1E'
     dump = sys.argv[sys.argv.index('--dump') + 1] if '--dump' in sys.argv else None
     lines = open(path).read().split('\n')
     start = None

@@ -67,13 +67,17 @@ def test_philox_requests():
     low = (w[0] & 0x7ff) | ((w[1] & 0x7ff) << 11) | ((w[2] & 0x3ff) << 22)
     assert L.orc_philox_request(42, 1000, 7, 3, 0, 4) == low / 2.0**32
     # unit-ball candidates: 21 bits per coordinate, one candidate per pair of words; the first block
-    # of a bounce = one candidate (words 0, 1) + the coin (word 2); a later block = two candidates
+    # of a bounce = one candidate (words 0, 1) + EITHER the coin (word 2; a bounce that draws one) OR a second
+    # candidate (words 2, 3; every other bounce); a later block = two candidates
     def ball(lo, hi):
         return [(lo >> 11) / 2.0**21, (hi >> 11) / 2.0**21, ((lo & 0x7ff) | ((hi & 0x3ff) << 11)) / 2.0**21]
     first = ball(w[0], w[1])
     for k in range(3):
         assert L.orc_philox_request(42, 1000, 7, 3, 2, k) == first[k]
     assert L.orc_philox_request(42, 1000, 7, 3, 2, 3) == w[2] / 2.0**32
+    second = ball(w[2], w[3])
+    for k in range(3):
+        assert L.orc_philox_request(42, 1000, 7, 3, 2, 4 + k) == second[k]
     later = ball(w[0], w[1]) + ball(w[2], w[3])
     for k in range(6):
         assert L.orc_philox_request(42, 1000, 7, 3, 3, k) == later[k]
