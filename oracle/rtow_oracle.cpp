@@ -245,7 +245,7 @@ struct PhiloxDraw {
   }
   // Unit-ball candidates: 21 bits per coordinate, one candidate per pair of words — x and y are
   // the top 21 bits of the two words, z the 11 + 10 low bits left over.  The first block of a
-  // bounce carries ONE candidate (words 0, 1) and the dielectric coin (word 2, 32 bits); every
+  // bounce carries a candidate (words 0, 1) and the dielectric coin (word 2, 32 bits) or a second candidate; every
   // further block carries two candidates, (w0, w1) and (w2, w3).
   static void ball_from_pair(uint32_t lo, uint32_t hi, double out[3]) {
     const double s21 = 0x1p-21;

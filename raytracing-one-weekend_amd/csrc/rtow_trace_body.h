@@ -42,8 +42,9 @@
 //     0), key = seed.  The first block of a sample carries the pixel jitter and the shutter
 //     time (21 bits each) AND the first lens-disk candidate (32 bits per coordinate); a
 //     further lens-disk block carries two candidates.  Unit-ball candidates have 21 bits per
-//     coordinate, one candidate per pair of words: the first block of a bounce carries one
-//     candidate and the dielectric coin (32 bits), every further block two candidates.
+//     coordinate, one candidate per pair of words: the first block of a bounce carries a candidate in
+//     words 0, 1 and either the dielectric coin (word 2, 32 bits) or — for a bounce that draws no coin —
+//     a second candidate in words 2, 3 (round 4); every further block two candidates.
 //     Whole blocks per request keep the rejection loops free of per-lane parity divergence;
 //     Philox is a large share of the kernel's VALU time, so blocks are not wasted (packing the
 //     lens candidates removed ~1.9 of the ~4 blocks a wave spends per trip on new camera rays:

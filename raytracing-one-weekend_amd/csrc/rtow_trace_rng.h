@@ -69,7 +69,8 @@ __device__ __forceinline__ void rng_disk2(Rng &g, uint32_t k0, uint32_t k1, real
 }
 // Unit-ball candidates: 21 bits per coordinate, one candidate per pair of words (x, y: the top 21
 // bits of the two words; z: the 11 + 10 low bits left over).  The first block of a bounce carries
-// one candidate (words 0, 1) and the dielectric coin (word 2, 32 bits); a further block carries two.
+// a candidate (words 0, 1) and EITHER the dielectric coin (word 2, 32 bits) OR, for a bounce that draws no coin, a
+// second candidate (words 2, 3); a further block carries two candidates.
 // The candidate as its three 21-bit integers (X, Y, Z) = 2^21 (x, y, z).  The rejection test of random_in_unit_sphere
 // (src/random-utils.cpp:23-29: length2 >= 1) runs on them: x*x + y*y + z*z >= 1 <=> X*X + Y*Y + Z*Z >= 2^42, and the
 // binary64 form is EXACT for these operands (each square has 42 significant bits, the sums stay below 2^44 multiples
