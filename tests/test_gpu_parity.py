@@ -676,11 +676,11 @@ def _fast_default_image(scene, cfg, _cache={}):
             code = (
                 "import sys, numpy as np; sys.path[:0] = %r\n"
                 "import rtow\n"
-                "scene = rtow.HostScene.cover(11, 1.5, True) if %d < 900 else rtow.HostScene.obj(%r, 16 / 9)\n"
+                "scene = rtow.HostScene.cover(11, 1.5, %r) if %d < 900 else rtow.HostScene.obj(%r, 16 / 9)\n"
                 "cfg = rtow.make_config(%d, %d, %d, 2, %d, seed=5, precision=rtow.F64_FAST)\n"
                 "img, st = rtow.Context(0).render(scene, cfg)\n"
                 "np.save(%r, img); open(%r, 'w').write(str(st.segments))\n"
-            ) % ([p for p in sys.path if p], scene.c.n_prims, str(GOLDEN / "suzanne.obj"), cfg.image_width, cfg.image_height,
+            ) % ([p for p in sys.path if p], scene.c.n_moving > 0, scene.c.n_prims, str(GOLDEN / "suzanne.obj"), cfg.image_width, cfg.image_height,
                  cfg.samples_per_pixel, cfg.max_child_rays, td + "/i.npy", td + "/s.txt")
             subprocess.run([sys.executable, "-c", code], check=True, env=env, capture_output=True)
             _cache[key] = (np.load(td + "/i.npy"), int(open(td + "/s.txt").read()))
@@ -694,10 +694,12 @@ def _fast_default_image(scene, cfg, _cache={}):
     {"RTOW_BVH4_SM": "1", "RTOW_SM4_VOTES": "64,64,64"},
     {"RTOW_BVH4_STACK_K": "2"},                                                      # nearly everything spills
     {"RTOW_NO_BVH4": "1"},                                                           # meshes on the binary walk
-], ids=["plain", "extreme", "sm4", "sm4-64", "spill", "bvh2"])
+    {"RTOW_NO_SPEC": "1"},                                                           # the generic GRID kernel instead of the scene-class specialisation
+], ids=["plain", "extreme", "sm4", "sm4-64", "spill", "bvh2", "generic-grid"])
 def test_scheduling_knobs_do_not_change_the_image(monkeypatch, env):
-    """Resumable walks, leaf / fetch quorums, the state-machine form of the BVH4 kernel and the size of the
-    LDS stack only decide WHEN a lane does its work: with any setting the strict image is the oracle's, bit
+    """Resumable walks, leaf / fetch quorums, the state-machine form of the BVH4 kernel, the size of the
+    LDS stack and the scene-class specialisation of the GRID kernel (static cover: SPEC 1, moving cover: SPEC 2,
+    against the generic instantiation) only decide WHEN a lane does its work or which dead code the kernel carries: with any setting the strict image is the oracle's, bit
     for bit, on the sphere scene (GRID) and on the mesh (BVH4), and the fast image is the fast image of the
     default setting.  (Knobs are read when a context is created.)"""
     for k, v in env.items():
@@ -706,6 +708,7 @@ def test_scheduling_knobs_do_not_change_the_image(monkeypatch, env):
     try:
         for scene, cfg in (
             (rtow.HostScene.cover(11, 1.5, True), rtow.make_config(240, 160, 8, 2, 50, seed=3, precision=rtow.F64_STRICT)),
+            (rtow.HostScene.cover(11, 1.5, False), rtow.make_config(240, 160, 8, 2, 50, seed=6, precision=rtow.F64_STRICT)),
             (rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9), rtow.make_config(320, 180, 8, 2, 20, seed=4, precision=rtow.F64_STRICT)),
         ):
             img, st = c.render(scene, cfg)
