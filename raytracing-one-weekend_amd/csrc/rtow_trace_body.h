@@ -720,6 +720,11 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       }
 
     }
+    // The random-number window — first Philox block, jitter / dielectric decision, rejection loop — is dense integer
+    // and f64 arithmetic with no memory access: it runs at the LOWEST issue priority, so that of the four waves of a SIMD
+    // those in a latency-bound stage (cell lists, the DDA's cell words, hit records) issue first and the arithmetic of
+    // this window fills the gaps they leave (stage_prio, rtow_trace_math.h; measured in DESIGN.md §4.7 d13).
+    stage_prio<kPrioRng>();
     // first block of the sample / of the bounce
     uint32_t o0 = anyv(0u), o1 = anyv(0u), o2 = anyv(0u), o3 = anyv(0u);
     if (do_regen) g.r = 0u;
@@ -797,6 +802,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         rej = ball_outside(cand);
       }
     }
+    stage_prio<kPrioStage>();
     if (do_scat) rnd = ball_point(cand);  // only the accepted candidate becomes a vector
     if constexpr (STAMPS) {  // what the wave ran: as many trips as its unluckiest lane needed
       uint32_t mx = rej_trips, sum = rej_trips;

@@ -186,6 +186,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
         stamps.leaf_lanes += (unsigned long long)__popcll(m_pending);
         if (m_pending != 0ull && (m_pending & ~stamps.primary) == 0ull) stamps.phases_cam += 1;
       }
+      stage_prio<kPrioLeaf>();  // a chain of three dependent LDS reads per list entry: first in line for the issue slots
       if (q0 != 0u) leaf_test<LDS, true, SPEC>(im, sc, off, q0 >> 8, q0 & 255u, ray, best, nprim, last_id);
       q0 = q1;
       q1 = 0u;
@@ -195,6 +196,7 @@ __device__ __forceinline__ Closest closest_hit_grid(const Image<LDS> &im, const 
       }
       tmax32 = round_up_f32(best.t);
       stamps.mark(RG_LEAF, m_pending);
+      stage_prio<kPrioStage>();
       if (suspend) {
         // a lane whose next cell starts beyond the hit it has just found is finished after all
         t_resume = (walking && !(t_entry > tmax32)) ? t_entry : 0.0f;

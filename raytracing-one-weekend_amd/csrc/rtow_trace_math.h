@@ -35,6 +35,19 @@ __device__ __forceinline__ T anyv(T) {
   return x;
 }
 __device__ __forceinline__ V3 anyv3() { return V3{anyv(real(0)), anyv(real(0)), anyv(real(0))}; }
+// Issue priority of the wave by STAGE (s_setprio, 0..3; one scalar instruction).  The kernel is bound by VALU issue and a
+// SIMD's waves are each in a different stage of their trip.  Left alone, the arbiter treats them alike; told which stage
+// is latency-bound (LDS chains: highest), which is mixed (the default) and which is pure arithmetic (the random-number
+// window: lowest), it lets the memory requests leave first and fills the wait with the arithmetic of the others.
+// Round 4, C2: +3.9 % (every other placement that was tried — a constant priority, the reverse order, priority by path
+// depth — measured the same as none or worse).  Scheduling only: the image cannot change.
+constexpr int kPrioRng = 0, kPrioStage = 2, kPrioLeaf = 3;
+template <int P>
+__device__ __forceinline__ void stage_prio() {
+#ifndef RTOW_NO_STAGE_PRIO
+  __builtin_amdgcn_s_setprio(P);
+#endif
+}
 template <class T>
 __device__ __forceinline__ Vec3<T> operator+(Vec3<T> a, Vec3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 template <class T>
