@@ -63,17 +63,13 @@ struct Builder {
   std::vector<int32_t> order; // permutation being partitioned
   HostBvh *out;
   // Big subtrees are built concurrently (the two children of a node are independent: they partition disjoint
-  // ranges of `order`, and a leaf's primitives are its range of `order`, so nothing is appended to shared vectors).
-  // Node numbers come from the primitive RANGE, not from a counter: the subtree over n primitives owns a contiguous
-  // region of 2n - 2 slots below its root — the children's pair first, then the left child's region, then the
-  // right's — so that concurrent subtrees write to disjoint stretches of the arrays (round 4: with pairs handed out
-  // by one atomic counter the threads' nodes interleaved, every cache line of the node arrays was shared, and 16
-  // threads were 1.5x faster than one; now 3.5x), a subtree's nodes are memory neighbours for the image builders
-  // that walk it afterwards, and neither the tree nor its numbering depends on the timing.  Slots a subtree does not
-  // need (its leaves hold more than one primitive) stay zero and are never linked.
+  // ranges of `order`, node pairs come from an atomic counter into preallocated arrays, and a leaf's primitives
+  // are its range of `order`, so nothing is appended to shared vectors).  The TREE does not depend on the
+  // timing; node numbers do, and the scene images renumber the nodes anyway.
+  std::atomic<int> next_node{1};
   std::atomic<int> max_depth{0};
-  int parallel_min = 2048;                   // primitives below which a subtree is built by its parent's thread
-  static constexpr int kParallelDepth = 6;   // up to 64 concurrent subtrees (the 96.8k-triangle mesh on the 16-core share of the GPU box: 12.3 ms at 4, 9.3 at 6)
+  int parallel_min = 4096;                   // primitives below which a subtree is built by its parent's thread
+  static constexpr int kParallelDepth = 4;   // up to 16 concurrent subtrees
   // tests: 1 = pretend no thread can be started (the std::system_error path below)
   int fail_thread_start = 0;
 #ifndef RTOW_SAH_BINS
@@ -95,8 +91,7 @@ struct Builder {
     out->link[(size_t)idx * 4 + 3] = 0;
   }
 
-  // `region`: first slot of the 2 (hi - lo) - 2 slots for the nodes below `idx`
-  void build(int idx, int lo, int hi, int parent, int depth, int region) {
+  void build(int idx, int lo, int hi, int parent, int depth) {
     for (int d = max_depth.load(std::memory_order_relaxed); depth > d && !max_depth.compare_exchange_weak(d, depth);) {
     }
     Box b, cb;
@@ -243,7 +238,7 @@ struct Builder {
         return cen[(size_t)p * 3 + ax] < cen[(size_t)q * 3 + ax];
       });
     }
-    const int left = region, region_l = region + 2, region_r = region + 2 * (mid - lo);
+    const int left = next_node.fetch_add(2);
     set_node(idx, b, left, 0, parent);
     if (n >= parallel_min && depth < kParallelDepth) {
       // A thread that cannot be started (process limit of the machine: std::async throws std::system_error)
@@ -252,42 +247,19 @@ struct Builder {
       bool started = false;
       try {
         if (fail_thread_start) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
-        other = std::async(std::launch::async, [this, left, lo, mid, idx, depth, region_l] { build(left, lo, mid, idx, depth + 1, region_l); });
+        other = std::async(std::launch::async, [this, left, lo, mid, idx, depth] { build(left, lo, mid, idx, depth + 1); });
         started = true;
       } catch (const std::system_error &) {
       }
-      if (!started) build(left, lo, mid, idx, depth + 1, region_l);
-      build(left + 1, mid, hi, idx, depth + 1, region_r);
+      if (!started) build(left, lo, mid, idx, depth + 1);
+      build(left + 1, mid, hi, idx, depth + 1);
       if (started) other.get();
     } else {
-      build(left, lo, mid, idx, depth + 1, region_l);
-      build(left + 1, mid, hi, idx, depth + 1, region_r);
+      build(left, lo, mid, idx, depth + 1);
+      build(left + 1, mid, hi, idx, depth + 1);
     }
   }
 };
-
-// fn(i0, i1) over [0, n) in up to 16 concurrent stretches of at least `min_stretch` items (one stretch: the caller's
-// thread alone).  Like the builder's subtrees: a thread that cannot be started is not an error, its stretch runs here.
-template <class F>
-inline void for_stretches(size_t n, size_t min_stretch, F &&fn) {
-  const size_t parts = std::min<size_t>(16, std::max<size_t>(1, n / std::max<size_t>(min_stretch, 1)));
-  if (parts <= 1) {
-    fn((size_t)0, n);
-    return;
-  }
-  std::vector<std::future<void>> started;
-  started.reserve(parts);
-  for (size_t p = 1; p < parts; ++p) {
-    const size_t i0 = n * p / parts, i1 = n * (p + 1) / parts;
-    try {
-      started.push_back(std::async(std::launch::async, [&fn, i0, i1] { fn(i0, i1); }));
-    } catch (const std::system_error &) {
-      fn(i0, i1);
-    }
-  }
-  fn((size_t)0, n / parts);
-  for (auto &f : started) f.get();
-}
 
 inline void pad_box(Box &b) {
   // slack ≫ any rounding in the f64 slab test, ≪ any visible geometry
@@ -305,7 +277,7 @@ inline void pad_box(Box &b) {
 inline void build_bvh(const std::vector<double> &sph, const std::vector<double> &sph_r,
                       const std::vector<double> &mov, const std::vector<double> &tri, HostBvh &out,
                       int leaf_max = 4, double c_trav = 0.0, double time0 = 0.0, double time1 = 1.0,
-                      int parallel_min = 2048, int fail_thread_start = 0) {
+                      int parallel_min = 4096, int fail_thread_start = 0) {
   using namespace bvh_detail;
   const int ns = (int)sph_r.size(), nm = (int)(mov.size() / 8), nt = (int)(tri.size() / 12);
   const int n = ns + nm + nt;
@@ -359,8 +331,8 @@ inline void build_bvh(const std::vector<double> &sph, const std::vector<double> 
   out.link.assign((size_t)std::max(2 * n, 1) * 4, 0);
   out.prim.clear();
   out.depth = 0;
-  if (n > 0) B.build(0, 0, n, -1, 0, 1);
-  const int used = std::max(2 * n - 1, 1);  // slots, not nodes: see Builder
+  if (n > 0) B.build(0, 0, n, -1, 0);
+  const int used = n > 0 ? B.next_node.load() : 1;
   out.box.resize((size_t)used * 6);
   out.link.resize((size_t)used * 4);
   out.prim.assign(B.order.begin(), B.order.end());
@@ -410,7 +382,7 @@ inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
                              const double cam_origin[3], SceneImage &img,
                              const std::vector<int32_t> &prim_mat = {},
                              const std::vector<unsigned char> &mats_bytes = {}) {
-  int n = (int)(bvh.link.size() / 4);
+  const int n = (int)(bvh.link.size() / 4);
   // the f32 slab test sees the ray origin and the planes rounded to f32: pad every box by
   // more than that rounding can move a plane or an origin anywhere in the scene
   double scale = 1.0;
@@ -450,7 +422,6 @@ inline void make_scene_image(const HostBvh &bvh, const std::vector<double> &sph,
       stack.push_back(left_first ? l : r);
     }
   }
-  n = (int)order.size();  // nodes, from here on (the arrays hold unlinked slots too: Builder)
   // subtree sizes (postorder over the new numbering: children have larger indices)
   std::vector<int> size(n, 1);
   for (int i = n - 1; i >= 0; --i) {

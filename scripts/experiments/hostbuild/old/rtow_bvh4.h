@@ -131,19 +131,13 @@ inline void make_bvh4_image(const HostBvh &bvh, const std::vector<double> &tri, 
     img.map_s[k] = 1000.0 / half_k;
   }
 
-  // (first_inner / first_rec: the node index its first inner child gets and the record slot of its first leaf
-  // triangle — running sums of the pass below, so that the second pass can write any node without the ones before it)
-  struct N4 { int child[4]; int n; uint32_t first_inner, first_rec; };  // BVH2 node ids of the children
+  struct N4 { int child[4]; int n; };  // BVH2 node ids of the children
   std::vector<N4> nodes;               // breadth-first
   std::vector<int> src;                // BVH2 node each BVH4 node expands
   std::vector<int> level;
-  nodes.reserve((size_t)n2 / 2 + 1);
-  src.reserve((size_t)n2 / 2 + 1);
-  level.reserve((size_t)n2 / 2 + 1);
   src.push_back(0);
   level.push_back(1);
   int depth = 1;
-  uint32_t recs = 0;
   // a single-leaf tree: one node whose only child is that leaf
   for (size_t i = 0; i < src.size(); ++i) {
     N4 n4;
@@ -169,16 +163,12 @@ inline void make_bvh4_image(const HostBvh &bvh, const std::vector<double> &tri, 
         n4.child[n4.n++] = l2 + 1;
       }
     }
-    n4.first_inner = (uint32_t)src.size();
-    n4.first_rec = recs;
     nodes.push_back(n4);
     for (int c = 0; c < n4.n; ++c)
       if (!is_leaf2(n4.child[c])) {
         src.push_back(n4.child[c]);
         level.push_back(level[i] + 1);
         depth = std::max(depth, level[i] + 1);
-      } else {
-        recs += (uint32_t)bvh.link[(size_t)n4.child[c] * 4 + 1];
       }
     if (src.size() > kBvh4MaxNodes) return;
   }
@@ -195,14 +185,12 @@ inline void make_bvh4_image(const HostBvh &bvh, const std::vector<double> &tri, 
   unsigned char *B = img.blob.data();
   if (!mats_bytes.empty()) std::memcpy(B + img.off_mats, mats_bytes.data(), mats_bytes.size());
 
-  // second pass: inner children get consecutive node indices in the order they were appended to `src`; leaves copy
-  // their records in leaf order.  Every node is written from its own running sums, so stretches of nodes are written
-  // concurrently (the 96.8k-triangle mesh: 646,000 planes and 9 MB of records, 10 of the image's 15 ms)
+  // second pass in the same breadth-first order: inner children get consecutive node indices in
+  // the order they were appended to `src`; leaves copy their records in leaf order
+  uint32_t next_inner = 1, next_rec = 0;
   const float inf = INFINITY;
-  auto write_nodes = [&](size_t i0, size_t i1) {
-  for (size_t i = i0; i < i1; ++i) {
+  for (size_t i = 0; i < n4count; ++i) {
     const N4 &n4 = nodes[i];
-    uint32_t next_inner = n4.first_inner, next_rec = n4.first_rec;
     float *f = reinterpret_cast<float *>(B + i * node_bytes);
     uint16_t *h = reinterpret_cast<uint16_t *>(B + i * node_bytes);
     uint32_t *cw = reinterpret_cast<uint32_t *>(B + i * node_bytes + child_off);
@@ -247,9 +235,7 @@ inline void make_bvh4_image(const HostBvh &bvh, const std::vector<double> &tri, 
       }
     }
   }
-  };
-  bvh_detail::for_stretches(n4count, 2048, write_nodes);
-  img.ok = src.size() == n4count && recs == nt;
+  img.ok = next_inner == n4count && next_rec == nt;
 }
 
 // What the kernel's termination and addressing rest on: child links point to LATER nodes (breadth-first
