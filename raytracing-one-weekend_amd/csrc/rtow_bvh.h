@@ -339,21 +339,26 @@ inline void build_bvh(const std::vector<double> &sph, const std::vector<double> 
       b.mx[k] = std::max(a0, a1) + r;
     }
   }
-  for (int i = 0; i < nt; ++i) {
-    Box &b = B.pb[ns + nm + i];
-    const double *t = &tri[(size_t)i * 12];
-    for (int k = 0; k < 3; ++k) {
-      const double a = t[k], bb = t[k] + t[3 + k], c = t[k] + t[6 + k];
-      b.mn[k] = std::min(a, std::min(bb, c));
-      b.mx[k] = std::max(a, std::max(bb, c));
-    }
-  }
-  for (int i = 0; i < n; ++i) {
-    pad_box(B.pb[i]);
-    for (int k = 0; k < 3; ++k) B.cen[(size_t)i * 3 + k] = 0.5 * (B.pb[i].mn[k] + B.pb[i].mx[k]);
-  }
+  // (triangles, padding, centroids and the identity order in concurrent stretches: 3 of the 96.8k-triangle mesh's 9 ms)
   B.order.resize(n);
-  for (int i = 0; i < n; ++i) B.order[i] = i;
+  for_stretches((size_t)nt, 8192, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) {
+      Box &b = B.pb[(size_t)ns + nm + i];
+      const double *t = &tri[i * 12];
+      for (int k = 0; k < 3; ++k) {
+        const double a = t[k], bb = t[k] + t[3 + k], c = t[k] + t[6 + k];
+        b.mn[k] = std::min(a, std::min(bb, c));
+        b.mx[k] = std::max(a, std::max(bb, c));
+      }
+    }
+  });
+  for_stretches((size_t)n, 8192, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) {
+      pad_box(B.pb[i]);
+      for (int k = 0; k < 3; ++k) B.cen[i * 3 + k] = 0.5 * (B.pb[i].mn[k] + B.pb[i].mx[k]);
+      B.order[i] = (int32_t)i;
+    }
+  });
   // at most 2n - 1 nodes; the arrays are cut to the nodes used afterwards
   out.box.assign((size_t)std::max(2 * n, 1) * 6, 0.0);
   out.link.assign((size_t)std::max(2 * n, 1) * 4, 0);
