@@ -1120,6 +1120,7 @@ int RTOW_CAT(trace_occupancy_, RTOW_SUFFIX)(int kernel, int block, unsigned lds_
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   hipFuncAttributes fa;
   if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return -1;
+  if (fa.sharedSizeBytes != 0) return -1;  // (the 4-wide walk addresses the dynamic LDS block from 0, rtow_trace_bvh4.h lds_read)
   const int regs = fa.numRegs > 0 ? fa.numRegs : 128;
   const int alloc = ((regs + 7) / 8) * 8;
   int waves_per_simd = 512 / alloc;
