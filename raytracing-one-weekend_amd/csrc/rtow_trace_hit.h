@@ -69,6 +69,20 @@ template <class T>
 __device__ __forceinline__ void triangle_test(Vec3<T> o, Vec3<T> d, Vec3<T> A, Vec3<T> e1, Vec3<T> e2, Vec3<T> n,
                                               int id, T tmin, Closest &best) {
   T det = -dot(d, n);
+#if defined(RTOW_FAST_MATH) && !defined(RTOW_TRI_DIVIDE)
+  // Fast builds: the same inequalities multiplied through by det (> 0 where they matter) — no reciprocal and no
+  // scaled u, v, t for the lanes that miss, which is nearly all of them; the one division is paid by a hit.
+  {
+    const Vec3<T> ao = o - A;
+    const Vec3<T> dao = cross(ao, d);
+    const T ud = dot(e2, dao), vd = -dot(e1, dao), td = dot(ao, n);
+    if (det >= T(1e-6) && td >= tmin * det && td <= (T)best.t * det && ud >= T(0.0) && vd >= T(0.0) && (ud + vd) <= det) {
+      best.t = (real)(td * fast_rcp(det));
+      best.prim = id;
+    }
+    return;
+  }
+#endif
   T invdet = fast_rcp(det);  // strict build: 1.0 / det
   Vec3<T> ao = o - A;
   Vec3<T> dao = cross(ao, d);
