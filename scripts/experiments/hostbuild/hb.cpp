@@ -2,7 +2,7 @@
 //   g++ -O3 -std=c++20 -pthread -I../../../raytracing-one-weekend_amd/csrc hb.cpp -o hb && ./hb mesh.obj
 // To time the builder as it was before (node pairs from one atomic counter):
 //   mkdir old && git show 7d9cecf^:raytracing-one-weekend_amd/csrc/rtow_bvh.h > old/rtow_bvh.h &&
-//   cp ../../../raytracing-one-weekend_amd/csrc/rtow_bvh4.h old/ && g++ ... -Iold hb.cpp
+//   git show 7d9cecf^:raytracing-one-weekend_amd/csrc/rtow_bvh4.h > old/rtow_bvh4.h && g++ ... -Iold hb.cpp
 // Measured on the GPU box's 16-core share, 96.8k-triangle mesh (scripts/make_mesh.py 10): before 19-20 ms build_bvh +
 // 16 ms image (serial build 41.6 ms); after 8.5-9.5 + 6.2 ms.
 #include <chrono>
