@@ -121,6 +121,17 @@ int main(int argc, char **argv) {
     }
     std::printf("serial, concurrent and thread-start-failure builds give one image (%zu bytes)\n", ref.size());
   }
+  {  // the concurrent-stretches helper of the image pass: every index once, whatever the split
+    for (size_t n : {(size_t)0, (size_t)1, (size_t)7, (size_t)1000, (size_t)4097}) {
+      std::vector<int> hits(n, 0);
+      rtow::bvh_detail::for_stretches(n, 16, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) hits[i] += 1;
+      });
+      for (size_t i = 0; i < n; ++i)
+        if (hits[i] != 1) return 40;
+    }
+    std::printf("for_stretches: every index exactly once for 0, 1, 7, 1000 and 4097 items\n");
+  }
   {  // one triangle: a single-leaf tree
     std::vector<double> one(tri.begin(), tri.begin() + 12), none;
     std::vector<int32_t> pmat(1, 0);
