@@ -237,16 +237,6 @@ __device__ __forceinline__ void bvh4_leaf(const Bvh4Reader<FULL> &im, const DevS
   const uint32_t first = (leaf & (kRefLeaf - 1u)) >> 2, count = (leaf & 3u) + 1u;
   for (uint32_t k = 0; k < count; ++k) {
     const uint32_t r = sc.b4_off_tri + 96u * (first + k);
-#if defined(RTOW_TRI_NO_N) && defined(RTOW_FAST_MATH)
-    if constexpr (!FULL) {
-      const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u);
-      const double e2z = im.template tri<double>(r + 64u);
-      ++nprim;
-      const V3d e1 = {t1.y, t2.x, t2.y}, e2 = {t3.x, t3.y, e2z};
-      triangle_test<double>(o64, d64, V3d{t0.x, t0.y, t1.x}, e1, e2, cross(e1, e2), (int)(first + k), RTOW_TMIN, best);
-      continue;
-    }
-#endif
     const vd2 t0 = im.t2(r), t1 = im.t2(r + 16u), t2 = im.t2(r + 32u), t3 = im.t2(r + 48u), t4 = im.t2(r + 64u),
               t5 = im.t2(r + 80u);
     ++nprim;
