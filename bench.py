@@ -22,7 +22,9 @@ visible.  Under `python -m torch.distributed.run … bench.py --gpus N` the rank
 from the environment.  `--backend gloo` rehearses the N > 1 path on a one-GPU box (every
 rank on cuda:0, collectives through host memory; at most 6 ranks).
 
-One JSON line on rank 0, with
+stdout of rank 0 carries ONE compact JSON line (under 4 KB: the contract's keys, `roofline`, `cpu_baseline` and a
+handful of scalars — raytracing-one-weekend_amd/benchline.py).  The full record of the run goes to `--details-out`
+(default gpurun_out/bench_details.json) and to stderr, with
   roofline      — the bound that BINDS: "valu_issue".  `frac` = issue utilisation x lane activity of the
                   trace kernel (share of the chip's vector lane-slots that carried an active lane's
                   instruction), from the committed PMC passes of this very kernel source (null when the
@@ -62,6 +64,7 @@ sys.path.insert(0, str(ROOT / "raytracing-one-weekend_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+import benchline  # noqa: E402
 import rtow  # noqa: E402
 import tiles  # noqa: E402
 
@@ -120,6 +123,10 @@ def parse():
                     help="gloo = rehearsal of the N>1 path with every rank on cuda:0 (1-GPU box)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dump-image", default="", help="rank 0: write the gathered f64 sums of the last step (.npy)")
+    ap.add_argument("--details-out", default="",
+                    help="rank 0: where the full record of the run goes (per-rank tables, per-leg rooflines, builders, "
+                         "multi-device handle); default gpurun_out/bench_details.json, the temp directory if that "
+                         "cannot be written.  stdout carries only the compact line (benchline.py)")
     return ap.parse_args()
 
 
@@ -366,7 +373,6 @@ def rooflines(scene, st, kernel_ms, rows, W, workload, precision):
                 "is bound by vector-instruction issue.  hbm_equivalent_streaming is the metric's nominal figure.",
     }
     return binding, valu, walk
-    return roof, valu, walk
 
 
 def timed_render_loop(ctx, cfg, d_ptr, stream, dev, steps, warmup):
@@ -508,6 +514,24 @@ def samples_per_item(ctx, cfg):
     pairs = (C.c_uint32 * 8)()
     n = L.rtow_debug_schedule(ctx._h, C.byref(cfg), pairs, 4)
     return int(pairs[1]) if n > 0 else 0
+
+
+def write_details(out, where):
+    """The full record of the run as a JSON file beside the compact line; returns the path written (repo-relative
+    when inside the repo) or None."""
+    cands = [Path(where)] if where else [ROOT / "gpurun_out" / "bench_details.json",
+                                         Path(tempfile.gettempdir()) / "rtow_bench_details.json"]
+    for p in cands:
+        try:
+            p.parent.mkdir(parents=True, exist_ok=True)
+            p.write_text(json.dumps(out, indent=1) + "\n")
+            try:
+                return str(p.resolve().relative_to(ROOT))
+            except ValueError:
+                return str(p)
+        except OSError:
+            continue
+    return None
 
 
 def main():
@@ -707,20 +731,33 @@ def main():
                 mh.upload(scene)
                 cfg_m = rtow.make_config(W, H, spp, nstreams, DEPTH, seed=SEED, precision=precision, kernel=kernel,
                                          tile_rows=tile_rows)
-                m8 = timed(lambda: rtow.check(L.rtow_multi_render_rgb8(mh._h, C2.byref(cfg_m), host8.ctypes.data_as(C2.c_void_p),
-                                                                      None), "rtow_multi_render_rgb8"))
-                m64 = timed(lambda: rtow.check(L.rtow_multi_render(mh._h, C2.byref(cfg_m), host.ctypes.data_as(C2.POINTER(C2.c_double)),
-                                                                   None), "rtow_multi_render"))
+                def timed_frames(fn):
+                    """mean seconds per frame and the mean of the handle's own breakdown over the same frames"""
+                    fn()
+                    acc = {}
+                    t1 = time.perf_counter()
+                    for _ in range(n_e2e):
+                        fn()
+                        for k, v in mh.frame_breakdown().items():  # (a dozen doubles: ~10 us, inside the timed loop)
+                            acc[k] = acc.get(k, 0.0) + v / n_e2e
+                    return (time.perf_counter() - t1) / n_e2e, {k: round(v, 4) for k, v in acc.items()}
+
+                m8, b8 = timed_frames(lambda: rtow.check(L.rtow_multi_render_rgb8(mh._h, C2.byref(cfg_m), host8.ctypes.data_as(C2.c_void_p),
+                                                                                  None), "rtow_multi_render_rgb8"))
+                m64, b64 = timed_frames(lambda: rtow.check(L.rtow_multi_render(mh._h, C2.byref(cfg_m), host.ctypes.data_as(C2.POINTER(C2.c_double)),
+                                                                               None), "rtow_multi_render"))
                 mh.close()
                 out["multi_handle"] = {
                     "devices": [dev.index], "use_rccl": True, "calls": n_e2e,
                     "rgb8": {"value": round(W * H * spp_eff / m8 / 1e6, 3), "ms_per_frame": round(m8 * 1e3, 4),
-                             "over_rtow_render_rgb8": round(e8 / m8, 4)},
+                             "over_rtow_render_rgb8": round(e8 / m8, 4), "breakdown_ms": b8,
+                             # what the handle adds to the device's own trace + reduce time, per frame
+                             "over_kernel_ms": round(m8 * 1e3 - b8.get("dev_trace", float("nan")), 4)},
                     "f64": {"value": round(W * H * spp_eff / m64 / 1e6, 3), "ms_per_frame": round(m64 * 1e3, 4),
-                            "over_rtow_render": round(e1 / m64, 4)},
-                    "region": "rtow_multi_render{_rgb8,}(): resident scene; per frame one trace launch, ONE ncclGather "
-                              "(one-rank communicator), rows placed by a kernel on the first device, ONE D2H straight "
-                              "into caller memory (src/render.cpp:176-186)",
+                            "over_rtow_render": round(e1 / m64, 4), "breakdown_ms": b64,
+                            "over_kernel_ms": round(m64 * 1e3 - b64.get("dev_trace", float("nan")), 4)},
+                    "region": "rtow_multi_render{_rgb8,}(): resident scene; per frame one hand-off to the workers, one trace "
+                              "launch, ONE ncclGather (one-rank communicator), one D2H into caller memory, one wait",
                 }
             except rtow.RtowError as e:  # (no librccl.so on this machine: the line says so instead of failing the bench)
                 out["multi_handle"] = {"error": str(e)}
@@ -774,6 +811,16 @@ def main():
             if not a.no_scale_projection:
                 out["scale_projection"] = scale_projection(ctx, W, H, DEPTH, precision, kernel, dev, stream,
                                                            out["scaling_base"]["value"])
+                # second column: the C++ product path's own per-frame cost on top of every rank's launch (measured on
+                # the one-device handle above: hand-off, gather of one rank, D2H, wait; an N-rank frame adds the
+                # placement kernel and the gather's xGMI time, which one device cannot show)
+                over = (out.get("multi_handle") or {}).get("rgb8", {}).get("over_kernel_ms")
+                if over is not None and over == over:
+                    out["scale_projection"]["handle_over_kernel_ms"] = over
+                    for b in out["scale_projection"]["by_n"]:
+                        proj = W * H * 500 / ((b["step_ms_max"] + over) * 1e-3) / 1e6
+                        b["projected_Msamples_per_s_with_handle"] = round(proj, 1)
+                        b["projected_efficiency_with_handle"] = round(proj / (b["n_gpus"] * out["scaling_base"]["value"]), 4)
         if world == 1 and a.workload == "cover" and not a.spp and not a.no_other_configs:
             out["other_configs"] = [other_config(n, a, dev, precision, s)
                                     for n, s in (("moving", 4), ("suzanne", 3), ("mesh100k", 2))]
@@ -783,7 +830,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        details_path = write_details(out, a.details_out)
+        sys.stderr.write("bench.py details: " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        os.write(json_fd, (benchline.dumps(benchline.compact_line(out, details_path)) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RTOW_ABI_VERSION 6
+#define RTOW_ABI_VERSION 7
 
 /* error codes */
 #define RTOW_OK 0
@@ -334,14 +334,32 @@ int rtow_render_multi(int32_t n_devices, const int32_t *device_ids, const rtow_s
  * image_height*image_width*3 bytes, equal to a one-device rtow_render_rgb8 of the same config.
  * If a rank cannot enqueue its side of the gather, every communicator is aborted (ncclCommAbort) before anything
  * is waited for, the call returns RTOW_EHIP and the handle refuses further frames: an error is a code, never a hang.
- * rtow_multi_build_info reports the first device's build (every device builds the same structures). */
+ * rtow_multi_build_info reports the first device's build (every device builds the same structures).
+ * A frame is ONE hand-off to the worker threads (trace launch, a meeting of the workers, each rank's side of the
+ * gather), the placement kernel only when there is more than one rank, one asynchronous copy into the caller's
+ * buffer and ONE wait, on the first device's stream (it is ordered behind every other rank's queue by events).
+ * rtow_multi_frame_breakdown: where the last successful frame's time went, RTOW_MULTI_BREAKDOWN_FIELDS doubles in
+ * milliseconds indexed by RTOW_MB_* (host clock around the call's stages; HIP events on the first device's stream
+ * for the device side); returns the number of fields written. */
 typedef struct rtow_multi rtow_multi;
+enum {
+  RTOW_MB_TOTAL = 0,           /* entry to return of rtow_multi_render* (host clock) */
+  RTOW_MB_HANDOFF_ENQUEUE = 1, /* buffers, the hand-off to the workers, until every rank has queued its frame */
+  RTOW_MB_PLACE_ENQUEUE = 2,   /* error collection, stream-wait events, the placement kernel's launch */
+  RTOW_MB_WAIT_AND_COPY = 3,   /* queueing the device-to-host copy + the one wait (device work still running included) */
+  RTOW_MB_WAIT_ONLY = 4,       /* RTOW_MULTI_D2H=blocking only: the wait before the blocking copy */
+  RTOW_MB_DEV_TRACE = 5,       /* first device: trace + reduce (+ write_color), events */
+  RTOW_MB_DEV_GATHER = 6,      /* first device: the gather (or the strips' copy), events */
+  RTOW_MB_DEV_PLACE_COPY = 7,  /* first device: waits for the other ranks, placement kernel, device-to-host copy, events */
+  RTOW_MULTI_BREAKDOWN_FIELDS = 8
+};
 int rtow_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_rccl, rtow_multi **out);
 int rtow_multi_set_builder(rtow_multi *m, int32_t builder);
 int rtow_multi_upload(rtow_multi *m, const rtow_scene_t *scene);
 int rtow_multi_build_info(rtow_multi *m, rtow_build_info_t *out);
 int rtow_multi_render(rtow_multi *m, const rtow_config_t *cfg, double *rgb_sums_host, rtow_stats_t *stats);
 int rtow_multi_render_rgb8(rtow_multi *m, const rtow_config_t *cfg, unsigned char *rgb8_host, rtow_stats_t *stats);
+int rtow_multi_frame_breakdown(rtow_multi *m, double *out_ms, int32_t n_fields);
 void rtow_multi_destroy(rtow_multi *m);
 
 /* ---- host-side scene construction (no GPU needed) --------------------------

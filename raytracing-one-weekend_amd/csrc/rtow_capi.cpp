@@ -157,6 +157,21 @@ int upload(DevBuf &b, const std::vector<T> &v) {
   return RTOW_OK;
 }
 
+// A small host block to a device address inside an upload: through the arena like upload() (the source may be a
+// stack buffer: an asynchronous copy must not read it after this returns), synchronously when the arena is full.
+int h2d_block(void *dst, const void *src, size_t n) {
+  PinnedArena *a = g_arena;
+  const size_t at = a ? (a->used + 255) / 256 * 256 : 0;
+  if (a && a->p && at + n <= a->cap) {
+    std::memcpy(a->p + at, src, n);
+    a->used = at + n;
+    HIPCHK(hipMemcpyAsync(dst, a->p + at, n, hipMemcpyHostToDevice, nullptr));
+  } else {
+    HIPCHK(hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+  }
+  return RTOW_OK;
+}
+
 // Scene image of the f32 build, derived from a binary64 image: the same prefix (nodes or
 // header+cells, then ids — everything before the sphere records), the binary64 sphere and moving
 // records (large-primitive list, BVH kernel, shading), binary32 triangle records (the only
@@ -444,6 +459,8 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   rtow::lbvh_release(c->lbvh_scratch);
   rtow::grid_build_release(c->grid_scratch);
+  // nothing of this context is pending in the runtime when the caller goes on (often: to exit())
+  (void)hipDeviceSynchronize();
   delete c;
 }
 
@@ -797,7 +814,7 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
         const uint32_t off_large = (uint32_t)(gimg.off_ids + total_ids * 4);
         rtow::write_grid_header(header, hd, gimg.n_large, off_large, gimg.off_fat, gimg.fat_stride);
         HIPCHK(hipMemsetAsync(gp, 0, gimg.total_bytes, nullptr));
-        HIPCHK(hipMemcpyAsync(gp, header, 64, hipMemcpyHostToDevice, nullptr));
+        if ((rc = h2d_block(gp, header, 64))) return rc;  // (`header` is on the stack: never the source of an async copy)
         if (ns) HIPCHK(hipMemcpyAsync(gp + gimg.off_sph, c->sph.p, sph.size() * 8, hipMemcpyDeviceToDevice, nullptr));
         if (nm) HIPCHK(hipMemcpyAsync(gp + gimg.off_mov, c->mov.p, mov.size() * 8, hipMemcpyDeviceToDevice, nullptr));
         if (nt) HIPCHK(hipMemcpyAsync(gp + gimg.off_tri, c->tri.p, tri.size() * 8, hipMemcpyDeviceToDevice, nullptr));
@@ -1696,5 +1713,11 @@ int rtow_debug_schedule(rtow_ctx *c, const rtow_config_t *cfg, uint32_t *out, in
 namespace rtow {
 // for rtow_multi.cpp: the sticky dropped-samples word of a context, read after its stream has been waited for
 int ctx_check_dropped(rtow_ctx *c) { return c ? check_dropped(c, false) : RTOW_OK; }
+int ctx_mirror_dropped(rtow_ctx *c, void *stream) { return c ? mirror_dropped(c, (hipStream_t)stream) : RTOW_OK; }
+int ctx_check_dropped_mirrored(rtow_ctx *c) {
+  if (!c) return RTOW_OK;
+  if (*c->h_dropped != 0ull) HIPCHK(hipSetDevice(c->device));  // (the error path resets the device word)
+  return check_dropped(c, true);
+}
 }  // namespace rtow
 

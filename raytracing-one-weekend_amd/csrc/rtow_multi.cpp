@@ -36,6 +36,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +54,8 @@
 namespace rtow {
 int set_last_error(int code, const char *fmt, ...);  // rtow_capi.cpp
 int ctx_check_dropped(rtow_ctx *c);                  // rtow_capi.cpp: samples given up at the end-of-launch bound
+int ctx_mirror_dropped(rtow_ctx *c, void *stream);   //   ... queue the copy of the sticky word into pinned memory
+int ctx_check_dropped_mirrored(rtow_ctx *c);         //   ... read the mirror (the stream has been waited for)
 int launch_place_rows(const void *gathered, void *image, uint32_t n_ranks, uint32_t max_rows, uint32_t row_bytes,
                       uint32_t height, uint32_t tile_rows, void *stream);  // rtow_reduce.hip
 }
@@ -67,7 +71,10 @@ struct Rccl {
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool load(std::string &why) {
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      // RTLD_NODELETE: never unloaded.  librccl.so registers its own device code objects with the HIP runtime when it is
+      // loaded and unregisters them from handlers that run when it is unloaded; unloading it in the middle of a process
+      // that goes on using HIP (or at exit, in an order nobody controls) is a teardown this library does not need.
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);
       if (lib) break;
     }
     if (!lib) {
@@ -93,7 +100,8 @@ struct Rank {
   hipStream_t stream = nullptr;
   void *d_local = nullptr;   // this rank's strips: [max_rows][W][3] f64 sums or bytes
   size_t local_bytes = 0;
-  hipEvent_t strips_ev = nullptr;  // use_rccl == 0: this rank's copy into the first device's gather buffer has been queued
+  hipEvent_t strips_ev = nullptr;  // everything this rank queues for a frame (trace, its side of the gather or its copy of
+                                   // the strips to the first device, the mirror of its dropped-samples word) has been queued
   ncclComm_t comm = nullptr;
   int err = RTOW_OK;
   std::string msg;
@@ -140,6 +148,14 @@ struct rtow_multi {
   size_t image_bytes = 0;
   bool comm_dead = false;    // a collective failed half-issued and the communicators were aborted: the handle renders no more
   int fail_gather_rank = -1; // RTOW_MULTI_FAIL_GATHER (tests): this rank's gather enqueue reports a failure without enqueuing
+  bool d2h_blocking = false; // RTOW_MULTI_D2H=blocking: wait for the first device's stream, then the runtime's blocking copy
+  // One frame = ONE worker hand-off.  Inside it the workers meet once (`arrived`): after every rank has queued its trace
+  // launch and before any queues its side of the collective, so that a rank that failed keeps all of them from enqueuing.
+  std::atomic<int> arrived{0};
+  std::atomic<int> failed{0};
+  // where the last frame's time went (rtow_multi_frame_breakdown): host clock + events on the first device's stream
+  hipEvent_t frame_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // before trace, after trace+reduce, after the gather, after placement + copy
+  double last_ms[RTOW_MULTI_BREAKDOWN_FIELDS] = {};
   // workers
   std::vector<std::thread> threads;
   std::mutex mu;
@@ -221,7 +237,9 @@ void rtow_multi_destroy(rtow_multi *m) {
     if (k.stream) (void)hipStreamDestroy(k.stream);
     rtow_ctx_destroy(k.ctx);
   }
-  if (m->rccl.lib) dlclose(m->rccl.lib);
+  if (m->rccl.lib) dlclose(m->rccl.lib);  // (drops the reference; RTLD_NODELETE keeps the library mapped)
+  for (hipEvent_t &e : m->frame_ev)
+    if (e) (void)hipEventDestroy(e);
   delete m;
 }
 
@@ -255,6 +273,7 @@ int rtow_multi_create(int32_t n_devices, const int32_t *device_ids, int32_t use_
       for (int r = 0; r < n_devices; ++r) m->ranks[(size_t)r].comm = comms[(size_t)r];
     }
     if (const char *e = std::getenv("RTOW_MULTI_FAIL_GATHER")) m->fail_gather_rank = std::atoi(e);
+    if (const char *e = std::getenv("RTOW_MULTI_D2H")) m->d2h_blocking = std::strcmp(e, "blocking") == 0;
     try {
       for (int r = 0; r < n_devices; ++r) m->threads.emplace_back([m, r] { m->worker(r); });
     } catch (...) {  // a thread could not be started: the ones that run are joined by destroy
@@ -351,50 +370,60 @@ static int multi_render(rtow_multi *m, const rtow_config_t *cfg, void *host_out,
     }
     const bool rccl = m->use_rccl;
     const bool want_stats = stats != nullptr;
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    const clk::time_point t0 = clk::now();
+    for (hipEvent_t &e : m->frame_ev)
+      if (!e && hipEventCreate(&e) != hipSuccess) return rtow::set_last_error(RTOW_EHIP, "%s: hipEventCreate", what);
+    m->arrived.store(0, std::memory_order_relaxed);
+    m->failed.store(0, std::memory_order_relaxed);
+    // ONE hand-off to the workers per frame.  Each worker: (1) queue this rank's trace (+ reduce / write_color) on its
+    // stream; (2) meet the others; (3) unless some rank failed, queue its side of the one collective (or, without RCCL,
+    // its copy of the strips to the first device), the mirror of its dropped-samples word, and an event behind all of it.
     m->run([m, cfg, n, count, bytes, rccl, want_stats, rgb8](int r) {
       Rank &me = m->ranks[(size_t)r];
-      if (!me.hip(hipSetDevice(me.device), "hipSetDevice")) return;
-      if (me.local_bytes < bytes) {
-        if (me.d_local) (void)hipFree(me.d_local);
-        me.d_local = nullptr;
-        me.local_bytes = 0;
-        if (!me.hip(hipMalloc(&me.d_local, bytes), "hipMalloc")) return;
-        me.local_bytes = bytes;
-      }
-      rtow_config_t mine = *cfg;
-      mine.rank = r;
-      mine.nranks = n;
-      const int rows = rtow_local_rows(&mine);
-      std::memset(&me.stats, 0, sizeof me.stats);
-      // ranks with fewer rows than rank 0: the rest of their strip buffer is defined (zero) for the gather
-      if ((size_t)rows * (size_t)cfg->image_width * 3 < count &&
-          !me.hip(hipMemsetAsync(me.d_local, 0, bytes, me.stream), "hipMemsetAsync"))
-        return;
-      if (rows > 0) {
-        const int rc = rgb8 ? rtow_render_device_rgb8(me.ctx, &mine, me.d_local, me.stream, want_stats ? &me.stats : nullptr)
-                            : rtow_render_device(me.ctx, &mine, me.d_local, me.stream, want_stats ? &me.stats : nullptr);
-        if (rc) return me.fail_with_last(rc, rgb8 ? "rtow_render_device_rgb8" : "rtow_render_device");
-      }
-      if (!rccl) {
-        // no collective (ranks on one device, where a communicator cannot exist): every rank copies its strips into
-        // its slot of the first device's gather buffer and marks the copy on its stream
-        unsigned char *slot = (unsigned char *)m->d_gather + (size_t)r * bytes;
-        const int dev0 = m->ranks[0].device;
-        if (!me.hip(me.device == dev0 ? hipMemcpyAsync(slot, me.d_local, bytes, hipMemcpyDeviceToDevice, me.stream)
-                                      : hipMemcpyPeerAsync(slot, dev0, me.d_local, me.device, bytes, me.stream),
-                    "copy of the strips to the first device"))
-          return;
-        me.hip(hipEventRecord(me.strips_ev, me.stream), "hipEventRecord");
-      }
-    });
-    int rc = m->collect(what);
-    if (rc == RTOW_OK && rccl) {
-      // the one collective, stream-ordered behind every rank's kernels: each rank's strip buffer to the first
-      // device.  One thread per device calls ncclGather on its own communicator and stream (the calls of a
-      // collective may come from different threads; each enqueues on its own stream).
-      m->run([m, count, rgb8](int r) {
-        Rank &me = m->ranks[(size_t)r];
+      auto phase1 = [&]() {
         if (!me.hip(hipSetDevice(me.device), "hipSetDevice")) return;
+        if (me.local_bytes < bytes) {
+          if (me.d_local) (void)hipFree(me.d_local);
+          me.d_local = nullptr;
+          me.local_bytes = 0;
+          if (!me.hip(hipMalloc(&me.d_local, bytes), "hipMalloc")) return;
+          me.local_bytes = bytes;
+        }
+        rtow_config_t mine = *cfg;
+        mine.rank = r;
+        mine.nranks = n;
+        const int rows = rtow_local_rows(&mine);
+        std::memset(&me.stats, 0, sizeof me.stats);
+        if (r == 0 && !me.hip(hipEventRecord(m->frame_ev[0], me.stream), "hipEventRecord")) return;
+        // ranks with fewer rows than rank 0: the rest of their strip buffer is defined (zero) for the gather
+        if ((size_t)rows * (size_t)cfg->image_width * 3 < count &&
+            !me.hip(hipMemsetAsync(me.d_local, 0, bytes, me.stream), "hipMemsetAsync"))
+          return;
+        if (rows > 0) {
+          const int rc = rgb8 ? rtow_render_device_rgb8(me.ctx, &mine, me.d_local, me.stream, want_stats ? &me.stats : nullptr)
+                              : rtow_render_device(me.ctx, &mine, me.d_local, me.stream, want_stats ? &me.stats : nullptr);
+          if (rc) return me.fail_with_last(rc, rgb8 ? "rtow_render_device_rgb8" : "rtow_render_device");
+        }
+        if (r == 0) me.hip(hipEventRecord(m->frame_ev[1], me.stream), "hipEventRecord");
+      };
+      try {
+        phase1();
+      } catch (const std::exception &e) {  // every worker must reach the meeting point
+        me.err = RTOW_EINVAL;
+        me.msg = e.what();
+      } catch (...) {
+        me.err = RTOW_EINVAL;
+        me.msg = "unknown C++ exception";
+      }
+      if (me.err) m->failed.fetch_add(1, std::memory_order_relaxed);
+      m->arrived.fetch_add(1, std::memory_order_acq_rel);
+      while (m->arrived.load(std::memory_order_acquire) < n) std::this_thread::yield();  // all n workers run this job
+      if (m->failed.load(std::memory_order_relaxed) != 0) return;  // nobody enqueues a collective some rank cannot join
+      if (rccl) {
+        // the one collective, stream-ordered behind every rank's kernels: each rank's strip buffer to the first device.
+        // One thread per device calls ncclGather on its own communicator and stream.
         const ncclResult_t res = r == m->fail_gather_rank
                                      ? ncclInternalError  // (test hook: this rank's side of the collective is never enqueued)
                                      : m->rccl.Gather(me.d_local, r == 0 ? m->d_gather : nullptr, count, rgb8 ? ncclUint8 : ncclDouble,
@@ -402,59 +431,100 @@ static int multi_render(rtow_multi *m, const rtow_config_t *cfg, void *host_out,
         if (res != ncclSuccess) {
           me.err = RTOW_EHIP;
           me.msg = std::string("ncclGather: ") + m->rccl.GetErrorString(res);
+          m->failed.fetch_add(1, std::memory_order_relaxed);
+          return;
         }
-      });
-      rc = m->collect(rgb8 ? "rtow_multi_render_rgb8 (gather)" : "rtow_multi_render (gather)");
-      if (rc != RTOW_OK) {
-        // A collective that one rank could not enqueue never completes on the ranks that did: waiting for their
-        // streams would hang.  Abort every communicator (in-flight kernels exit), do not wait, and refuse further
-        // frames on this handle: the error is an error code, never a wait.
-        const std::string keep = rtow_last_error();
-        for (Rank &k : m->ranks) {
-          if (k.comm) {
-            (void)hipSetDevice(k.device);
-            (void)m->rccl.CommAbort(k.comm);
-            k.comm = nullptr;
-          }
-        }
-        m->comm_dead = true;
-        return rtow::set_last_error(rc, "%s (communicators aborted)", keep.c_str());
+      } else {
+        // no collective (ranks on one device, where a communicator cannot exist): every rank copies its strips into
+        // its slot of the first device's gather buffer
+        unsigned char *slot = (unsigned char *)m->d_gather + (size_t)r * bytes;
+        const int dev0 = m->ranks[0].device;
+        if (!me.hip(me.device == dev0 ? hipMemcpyAsync(slot, me.d_local, bytes, hipMemcpyDeviceToDevice, me.stream)
+                                      : hipMemcpyPeerAsync(slot, dev0, me.d_local, me.device, bytes, me.stream),
+                    "copy of the strips to the first device"))
+          return;
       }
+      if (r == 0 && !me.hip(hipEventRecord(m->frame_ev[2], me.stream), "hipEventRecord")) return;
+      const int drc = rtow::ctx_mirror_dropped(me.ctx, me.stream);
+      if (drc) return me.fail_with_last(drc, "mirror of the dropped-samples word");
+      if (r != 0) me.hip(hipEventRecord(me.strips_ev, me.stream), "hipEventRecord");
+    });
+    const double t_handoff = ms_since(t0);
+    const bool gather_failed = rccl && m->failed.load(std::memory_order_relaxed) != 0;
+    bool gather_half_issued = false;
+    if (gather_failed)  // did any rank enqueue its side?  (phase-1 failures leave every rank before the collective)
+      for (int r = 0; r < n; ++r) gather_half_issued |= m->ranks[(size_t)r].msg.rfind("ncclGather", 0) == 0;
+    int rc = m->collect(what);
+    if (rc != RTOW_OK && gather_half_issued) {
+      // A collective that one rank could not enqueue never completes on the ranks that did: waiting for their
+      // streams would hang.  Abort every communicator (in-flight kernels exit), do not wait, and refuse further
+      // frames on this handle: the error is an error code, never a wait.
+      const std::string keep = rtow_last_error();
+      for (Rank &k : m->ranks) {
+        if (k.comm) {
+          (void)hipSetDevice(k.device);
+          (void)m->rccl.CommAbort(k.comm);
+          k.comm = nullptr;
+        }
+      }
+      m->comm_dead = true;
+      return rtow::set_last_error(rc, "%s (gather; communicators aborted)", keep.c_str());
     }
+    Rank &r0 = m->ranks[0];
+    const void *d_frame = m->d_gather;  // one rank: its strips ARE the image, rows in place
     if (rc == RTOW_OK) {
-      // on the first device, behind the strips' arrival: rows into place, then the ONE device-to-host copy, straight
-      // into the caller's buffer
-      Rank &r0 = m->ranks[0];
+      // on the first device, behind the strips' arrival (and behind everything the other ranks queued): rows into
+      // place, then the ONE device-to-host copy, straight into the caller's buffer
       hipError_t e = hipSetDevice(r0.device);
-      if (!rccl)
-        for (int r = 1; r < n && e == hipSuccess; ++r) e = hipStreamWaitEvent(r0.stream, m->ranks[(size_t)r].strips_ev, 0);
-      if (e == hipSuccess) {
+      for (int r = 1; r < n && e == hipSuccess; ++r) e = hipStreamWaitEvent(r0.stream, m->ranks[(size_t)r].strips_ev, 0);
+      if (e == hipSuccess && n > 1) {
         const int lrc = rtow::launch_place_rows(m->d_gather, m->d_image, (uint32_t)n, (uint32_t)max_rows, (uint32_t)row_bytes,
                                                 (uint32_t)H, (uint32_t)cfg->tile_rows, r0.stream);
         if (lrc != 0) e = (hipError_t)lrc;
+        d_frame = m->d_image;
       }
       if (e != hipSuccess) rc = rtow::set_last_error(RTOW_EHIP, "%s: placement on device %d: %s", what, r0.device, hipGetErrorString(e));
     }
-    // wait for every stream (the first device's placement kernel is the last thing queued)
-    for (int r = 0; r < n; ++r) {
-      Rank &me = m->ranks[(size_t)r];
-      (void)hipSetDevice(me.device);
-      const hipError_t e = hipStreamSynchronize(me.stream);
-      if (e != hipSuccess && rc == RTOW_OK)
-        rc = rtow::set_last_error(RTOW_EHIP, "rank %d (device %d): hipStreamSynchronize: %s", r, me.device, hipGetErrorString(e));
+    if (rc != RTOW_OK) {
+      // a failed frame still leaves every stream idle before it returns
+      const std::string keep = rtow_last_error();
+      for (int r = 0; r < n; ++r) {
+        (void)hipSetDevice(m->ranks[(size_t)r].device);
+        (void)hipStreamSynchronize(m->ranks[(size_t)r].stream);
+      }
+      return rtow::set_last_error(rc, "%s", keep.c_str());
     }
-    if (rc != RTOW_OK) return rc;
+    // The first device's stream is the only one to wait for: it is ordered behind every other rank's event.  The copy
+    // goes straight into the caller's (pageable) buffer.
+    const clk::time_point t1 = clk::now();
+    double t_wait = 0.0;
+    hipError_t e = hipSuccess;
+    if (m->d2h_blocking) {
+      e = hipStreamSynchronize(r0.stream);
+      t_wait = ms_since(t1);
+      if (e == hipSuccess) e = hipMemcpy(host_out, d_frame, image_bytes, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipEventRecord(m->frame_ev[3], r0.stream);
+    } else {
+      e = hipMemcpyAsync(host_out, d_frame, image_bytes, hipMemcpyDeviceToHost, r0.stream);
+      if (e == hipSuccess) e = hipEventRecord(m->frame_ev[3], r0.stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(r0.stream);
+    if (e != hipSuccess)
+      return rtow::set_last_error(RTOW_EHIP, "%s: copy of the frame from device %d: %s", what, r0.device, hipGetErrorString(e));
+    const double t_done = ms_since(t0);
+    for (int r = 0; r < n; ++r)  // never RTOW_OK with samples dropped (the end-of-launch bound of the trace kernel)
+      if ((rc = rtow::ctx_check_dropped_mirrored(m->ranks[(size_t)r].ctx))) return rc;
     {
-      // the ONE device-to-host copy, straight into the caller's (pageable) buffer: the runtime's own blocking copy —
-      // what rtow_render / rtow_render_rgb8 use; the asynchronous form into pageable memory measured 0.25 ms slower per
-      // frame, a pinned landing buffer plus a host pass slower still (rtow_capi.cpp)
-      (void)hipSetDevice(m->ranks[0].device);
-      const hipError_t e = hipMemcpy(host_out, m->d_image, image_bytes, hipMemcpyDeviceToHost);
-      if (e != hipSuccess) return rtow::set_last_error(RTOW_EHIP, "%s: copy of the frame from device %d: %s", what, m->ranks[0].device, hipGetErrorString(e));
-    }
-    for (int r = 0; r < n; ++r) {  // never RTOW_OK with samples dropped (the end-of-launch bound of the trace kernel)
-      (void)hipSetDevice(m->ranks[(size_t)r].device);
-      if ((rc = rtow::ctx_check_dropped(m->ranks[(size_t)r].ctx))) return rc;
+      double *b = m->last_ms;
+      float f = 0.f;
+      b[RTOW_MB_HANDOFF_ENQUEUE] = t_handoff;
+      b[RTOW_MB_PLACE_ENQUEUE] = std::chrono::duration<double, std::milli>(t1 - t0).count() - t_handoff;
+      b[RTOW_MB_WAIT_AND_COPY] = t_done - std::chrono::duration<double, std::milli>(t1 - t0).count();
+      b[RTOW_MB_WAIT_ONLY] = t_wait;
+      b[RTOW_MB_DEV_TRACE] = hipEventElapsedTime(&f, m->frame_ev[0], m->frame_ev[1]) == hipSuccess ? f : -1.0;
+      b[RTOW_MB_DEV_GATHER] = hipEventElapsedTime(&f, m->frame_ev[1], m->frame_ev[2]) == hipSuccess ? f : -1.0;
+      b[RTOW_MB_DEV_PLACE_COPY] = hipEventElapsedTime(&f, m->frame_ev[2], m->frame_ev[3]) == hipSuccess ? f : -1.0;
+      b[RTOW_MB_TOTAL] = ms_since(t0);
     }
     if (stats) {
       for (int r = 0; r < n; ++r) {
@@ -481,6 +551,12 @@ int rtow_multi_render_rgb8(rtow_multi *m, const rtow_config_t *cfg, unsigned cha
   if (cfg && cfg->nstreams > 0 && cfg->samples_per_pixel / cfg->nstreams <= 0)
     return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_render_rgb8: no effective samples (samples_per_pixel < nstreams)");
   return multi_render(m, cfg, rgb8_host, stats, true);
+}
+
+int rtow_multi_frame_breakdown(rtow_multi *m, double *out, int32_t n) {
+  if (!m || !out || n < 0) return rtow::set_last_error(RTOW_EINVAL, "rtow_multi_frame_breakdown: NULL argument");
+  for (int i = 0; i < n && i < RTOW_MULTI_BREAKDOWN_FIELDS; ++i) out[i] = m->last_ms[i];
+  return n < RTOW_MULTI_BREAKDOWN_FIELDS ? n : RTOW_MULTI_BREAKDOWN_FIELDS;
 }
 
 // The one-shot form: everything above for a single frame (set-up dominates it: use the handle for more than one).

@@ -17,7 +17,7 @@ PKG_DIR = Path(__file__).resolve().parent
 REPO_ROOT = PKG_DIR.parent
 LIB_PATH = Path(os.environ.get("RTOW_LIB", PKG_DIR / "librtow.so"))  # RTOW_LIB: A/B against another build
 
-RTOW_ABI_VERSION = 6
+RTOW_ABI_VERSION = 7
 RTOW_OK, RTOW_EINVAL, RTOW_ENODEV, RTOW_EHIP, RTOW_ENOSCENE, RTOW_EEMPTY, RTOW_ENOMEM = 0, -1, -2, -3, -4, -5, -6
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
@@ -107,8 +107,10 @@ EXPORTS = [
     "rtow_debug_schedule", "rtow_host_scene_cover_model", "rtow_host_scene_obj_model",
     "rtow_multi_create", "rtow_multi_set_builder", "rtow_multi_upload", "rtow_multi_build_info",
     "rtow_multi_render", "rtow_multi_destroy", "rtow_host_reftree_info",
-    "rtow_render_device_rgb8", "rtow_multi_render_rgb8",
+    "rtow_render_device_rgb8", "rtow_multi_render_rgb8", "rtow_multi_frame_breakdown",
 ]
+MULTI_BREAKDOWN = ("total", "handoff_enqueue", "place_enqueue", "wait_and_copy", "wait_only", "dev_trace", "dev_gather",
+                   "dev_place_copy")  # RTOW_MB_* of include/rtow.h, milliseconds
 
 
 class RtowError(RuntimeError):
@@ -440,6 +442,16 @@ class MultiContext:
         check(lib().rtow_multi_render_rgb8(self._h, C.byref(cfg), out.ctypes.data_as(C.c_void_p),
                                            C.byref(st) if st is not None else None), "rtow_multi_render_rgb8")
         return out, st
+
+    def frame_breakdown(self) -> dict:
+        """Where the last frame's time went (rtow_multi_frame_breakdown), milliseconds by name."""
+        v = (C.c_double * len(MULTI_BREAKDOWN))()
+        L = lib()
+        L.rtow_multi_frame_breakdown.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32]
+        n = L.rtow_multi_frame_breakdown(self._h, v, len(MULTI_BREAKDOWN))
+        if n < 0:
+            check(n, "rtow_multi_frame_breakdown")
+        return {k: float(v[i]) for i, k in enumerate(MULTI_BREAKDOWN[:n])}
 
     def close(self):
         if self._h:

@@ -43,6 +43,28 @@ def test_bench_spawns_ranks_and_the_gathered_frame_is_the_one_rank_frame(ctx, tm
     assert np.array_equal(got, whole), int((got != whole).sum())
 
 
+def test_bench_stdout_is_one_compact_line_and_the_details_go_to_a_file(tmp_path):
+    """The driver reads the LAST line of stdout as JSON (BENCH_r04: `parsed: null` on a 20.9 KB line).  stdout of the
+    bench is exactly one line under benchline.LINE_CAP with roofline and the contract's keys; everything else is in
+    the details file the line names."""
+    import benchline
+
+    det = tmp_path / "details.json"
+    r = run_bench(["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-scale-projection", "--details-out", str(det)])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.endswith("\n") and r.stdout.count("\n") == 1, r.stdout[:400]
+    assert len(r.stdout.encode()) < benchline.LINE_CAP
+    line = json.loads(r.stdout)
+    for key in benchline.CONTRACT_KEYS:
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["config"]["baseline_config"] == "configs[1]" and line["dtype"] == "f64"
+    assert line["roofline"]["bound"] == "valu_issue" and 0 < line["roofline"]["kernel_ms"] <= line["ms_per_step"]
+    assert line["details"] == str(det)
+    details = json.loads(det.read_text())
+    assert details["value"] == line["value"] and len(details["other_configs"]) == 4
+    assert benchline.compact_line(details, str(det)) == line
+
+
 def test_bench_refuses_more_gpus_than_the_box_has():
     import torch
 

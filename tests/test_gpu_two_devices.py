@@ -81,6 +81,10 @@ def test_multi_handle_rgb8_bytes_equal_the_one_device_bytes(ctx, devices, use_rc
             assert none is None and np.array_equal(again, one8)
             sums, _ = m.render(cfg)  # the f64 form goes through the same placement kernel
             assert np.array_equal(sums, ctx.render(scene, cfg)[0])
+            b = m.frame_breakdown()  # where that frame's time went: every stage non-negative, the parts within the total
+            assert set(b) == set(rtow.MULTI_BREAKDOWN) and all(v >= 0 for v in b.values()), b
+            assert b["handoff_enqueue"] + b["place_enqueue"] + b["wait_and_copy"] <= b["total"] + 1e-6
+            assert b["dev_trace"] > 0 and b["dev_trace"] <= b["total"]
     finally:
         m.close()
 
@@ -108,6 +112,26 @@ def test_failed_gather_enqueue_is_an_error_code_and_the_handle_refuses_further_f
         assert np.array_equal(ok.render(cfg)[0], ctx.render(scene, cfg)[0])
     finally:
         ok.close()
+
+
+@needs_two
+def test_gather_that_only_one_of_two_ranks_enqueued_returns_an_error_and_close_returns(monkeypatch):
+    """RTOW_MULTI_FAIL_GATHER=1 on two devices: rank 0 enqueues its side of the collective, rank 1 does not — the
+    half-issued case the abort exists for.  The frame returns RTOW_EHIP without waiting for the stream that can never
+    finish, the handle refuses further frames, and close() (which waits for the streams after the abort) returns."""
+    scene = rtow.HostScene.cover(11, 1.5, False)
+    monkeypatch.setenv("RTOW_MULTI_FAIL_GATHER", "1")
+    m = rtow.MultiContext([0, 1], use_rccl=True)
+    monkeypatch.delenv("RTOW_MULTI_FAIL_GATHER")
+    try:
+        m.upload(scene)
+        cfg = rtow.make_config(96, 64, 8, 2, 30, seed=7, precision=rtow.F64_FAST)
+        with pytest.raises(rtow.RtowError, match="ncclGather"):
+            m.render_rgb8(cfg)
+        with pytest.raises(rtow.RtowError, match="aborted"):
+            m.render(cfg)
+    finally:
+        m.close()
 
 
 @needs_two

@@ -125,22 +125,101 @@ def test_cli_dry_run_prints_the_reference_config_text():
     assert r.returncode != 0 and "not expected" in r.stderr
 
 
-def test_committed_bench_line_follows_the_contract():
-    """The bench line committed under profiles/ has every field the driver's contract names, is
-    consistent with BASELINE.json, and carries the roofline and cpu_baseline objects."""
+def test_rtweekend_names_the_frames_of_a_fatal_signal_and_keeps_the_signal_as_exit_status():
+    """Round 4 lost one `rtweekend` run to a SIGSEGV after the image was complete and had no frame to show for it; the
+    answer then was `_Exit(0)`.  Now main returns like the reference's (src/main.cpp:165-170) and a fatal signal writes
+    the phase and a raw backtrace to stderr before it is re-raised with the default action: the exit status is still
+    the signal's (no masking), and the next occurrence in any ordinary run names where it was."""
+    import signal
+
+    exe = REPO / "raytracing-one-weekend_amd" / "rtweekend"
+    src = (REPO / "raytracing-one-weekend_amd" / "host" / "main.cpp").read_text()
+    assert "_Exit" not in src and "quick_exit" not in src
+    r = subprocess.run([str(exe), "-w", "16", "-s", "4", "-t", "1", "-n", "0"], capture_output=True, text=True,
+                       env=dict(__import__("os").environ, RTOW_TEST_RAISE=str(int(signal.SIGSEGV))))
+    assert r.returncode == -signal.SIGSEGV, r.returncode
+    assert "fatal signal 11" in r.stderr and "phase: parsing flags" in r.stderr
+    assert "backtrace" in r.stderr and "rtweekend" in r.stderr.split("backtrace", 1)[1]  # at least its own frame
+    assert not r.stdout
+
+
+def _check_compact_line(line, raw_len):
+    """The contract of the ONE line bench.py prints (benchline.py): under the cap, exactly the agreed keys."""
     import json
 
+    import benchline
+
     base = json.loads((REPO / "BASELINE.json").read_text())
-    line = json.loads((REPO / "profiles" / "r01_f_bench_final.json").read_text())
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+    assert raw_len < benchline.LINE_CAP
+    for key in benchline.CONTRACT_KEYS:
         assert key in line, key
+    assert set(line) <= set(benchline.CONTRACT_KEYS) | {"value_e2e", "scaling_base_value", "projected_efficiency_n8",
+                                                        "projected_efficiency_n8_with_handle", "multi_handle", "other",
+                                                        "details"}
+    assert set(line["config"]) == set(benchline.CONFIG_KEYS)
+    assert set(line["roofline"]) == set(benchline.ROOFLINE_KEYS) | {"hbm_equivalent_GBps"}
     assert line["metric"] == base["metric"] and line["unit"] == "Msamples/s"
-    assert line["dtype"] == "f64" and line["vs_baseline"] is None and line["higher_is_better"] is True
-    assert "workload" in line["config"] and "1200x800, 100 spp, 50 bounces" in line["config"]["workload"]
+    assert line["vs_baseline"] is None and line["higher_is_better"] is True
+    assert not any(isinstance(v, (dict, list)) for v in (line["other"] or {}).values())  # plain numbers
+    assert all(len(v) <= 240 for v in _strings(line)), "prose belongs in DESIGN.md, not in the line"
+
+
+def _strings(o):
+    if isinstance(o, str):
+        yield o
+    elif isinstance(o, dict):
+        for v in o.values():
+            yield from _strings(v)
+    elif isinstance(o, list):
+        for v in o:
+            yield from _strings(v)
+
+
+def test_compact_bench_line_from_committed_details_stays_under_the_cap():
+    """BENCH_r04.json had `parsed: null`: the one line had grown to 20.9 KB.  bench.py now prints
+    benchline.compact_line(details) and writes the details to a file.  Built here from the committed details of the
+    driver's command (rounds 4 and 5): under 4 KB, the contract's keys, roofline and cpu_baseline as objects,
+    everything else scalars."""
+    import json
+
+    import benchline
+
+    for name in ("r04_bench_driver_style.json", "r05_bench_details.json"):
+        f = REPO / "profiles" / name
+        if not f.exists():
+            continue
+        details = json.loads(f.read_text())
+        line = benchline.compact_line(details, "gpurun_out/bench_details.json")
+        raw = benchline.dumps(line)
+        assert "\n" not in raw
+        _check_compact_line(json.loads(raw), len(raw.encode()))
+        assert line["value"] == details["value"] and line["roofline"]["frac"] == details["roofline"]["frac"]
+        assert line["cpu_baseline"]["kind"] in ("port", "reference") and line["cpu_baseline"]["cores"] >= 1
+        assert line["other"]["mesh100k"] > 0 and line["other"]["stream_stress"] > 0
+    # a line that outgrows the cap is an error, not a silently unparsed record
+    fat = benchline.compact_line(details, "x" * 5000)
+    with pytest.raises(ValueError):
+        benchline.dumps(fat)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The compact line committed under profiles/ (the driver's command, final sources of the round) has every
+    field the driver's contract names, is consistent with BASELINE.json, and carries roofline and cpu_baseline."""
+    import json
+
+    f = REPO / "profiles" / "r05_bench_line.json"
+    if not f.exists():
+        pytest.skip("no round-5 line committed yet")
+    raw = f.read_text().strip()
+    assert raw.count("\n") == 0
+    line = json.loads(raw)
+    _check_compact_line(line, len(raw.encode()))
+    assert line["dtype"] == "f64" and line["n_gpus"] == 1
+    assert "1200x800, 100 spp, 50 bounces" in line["config"]["workload"] and line["config"]["baseline_config"] == "configs[1]"
     r = line["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["bound"] == "valu_issue" and r["peak"] == 1.0 and r["kernel_ms"] <= line["ms_per_step"]
+    if r["frac"] is not None:
+        assert abs(r["frac"] - min(r["issue_utilisation"], 1.0) * r["lane_activity"]) < 1e-3
     samples = 1200 * 800 * line["config"]["spp_effective"]
     assert abs(line["value"] - samples / (line["ms_per_step"] * 1e-3) / 1e6) / line["value"] < 1e-3
     c = line["cpu_baseline"]
