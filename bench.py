@@ -450,11 +450,29 @@ def other_config(name, a, dev, precision, steps, stress=False):
             e2e[bname] = {"value": round(W * H * spp / dt / 1e6, 3), "ms_per_call": round(dt * 1e3, 3),
                           "build_ms": round(bi2.bvh_build_ms + bi2.grid_build_ms, 3), "upload_ms": round(bi2.upload_ms, 3),
                           "bvh4_nodes": bi2.bvh4_nodes, "bvh4_node_bytes": bi2.bvh4_node_bytes}
-        ctx.set_builder(rtow.BUILDER_HOST_SAH)
         best = max(e2e, key=lambda k: e2e[k]["value"])
         line["end_to_end_rgb8"] = dict(e2e, best_builder=best, value_e2e=e2e[best]["value"],
                                        region="rtow_render_rgb8(): upload + acceleration build + trace + reduce + "
                                               "write_color + D2H of W*H*3 bytes, per call")
+        # the same call at a LOW sample count (32 spp; the reference's default is 20, src/render.h:15), where the host
+        # build is a large share of the frame: host, device, and what RTOW_BUILDER_AUTO (the context's default) picks
+        cfg_lo = rtow.make_config(W, H, 32, 2, depth, seed=SEED, precision=precision, kernel=rtow.KERNEL_AUTO)
+        lo = {}
+        for bname, b in (("host_sah", rtow.BUILDER_HOST_SAH), ("device_lbvh", rtow.BUILDER_DEVICE_LBVH), ("auto", rtow.BUILDER_AUTO)):
+            ctx.set_builder(b)
+            ts = []
+            for i in range(4):
+                t0 = time.perf_counter()
+                rtow.check(L.rtow_render_rgb8(ctx._h, C.byref(scene.c), C.byref(cfg_lo), host8.ctypes.data_as(C.c_void_p), None),
+                           "rtow_render_rgb8")
+                ts.append(time.perf_counter() - t0)
+            dt = sum(ts[1:]) / 3
+            bi2 = ctx.build_info()
+            lo[bname] = {"value": round(W * H * 32 / dt / 1e6, 3), "ms_per_call": round(dt * 1e3, 3),
+                         "build_ms": round(bi2.bvh_build_ms + bi2.grid_build_ms, 3),
+                         "builder_used": "device" if bi2.builder == rtow.BUILDER_DEVICE_LBVH else "host"}
+        line["end_to_end_rgb8_32spp"] = lo
+        ctx.set_builder(rtow.BUILDER_HOST_SAH)
     ctx.close()
     del out
     return line

@@ -52,6 +52,8 @@ def _other(details):
             out["mesh100k"] = o.get("value")
             out["mesh100k_e2e"] = _get(o, "end_to_end_rgb8", "value_e2e")
             out["mesh100k_frac"] = _get(o, "roofline", "frac")
+            out["mesh100k_e2e_32spp_auto"] = _get(o, "end_to_end_rgb8_32spp", "auto", "value")
+            out["mesh100k_e2e_32spp_host"] = _get(o, "end_to_end_rgb8_32spp", "host_sah", "value")
     return out or None
 
 

@@ -18,6 +18,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "rtow_device.h"
 
 namespace rtow {
@@ -46,9 +48,20 @@ struct Scratch {
   int32_t *b4_child = nullptr;  // [capacity][4] the children as radix-tree refs (kB4Empty = none)
   uint32_t *b4_cw = nullptr;    // [capacity][4] child words of the image (rtow_bvh4.h: ref21)
   uint32_t *b4_cnt = nullptr, *b4_pos = nullptr;  // [capacity] inner children per node of a level, their exclusive scan
+  uint32_t *b4_seen = nullptr;  // [2 * capacity] validation: references per triangle record and per node
   void *scan_tmp = nullptr;
   size_t scan_tmp_bytes = 0;
   int b4_nodes = 0, b4_depth = 0;
+  // PLOC (round 5): the cluster array in two copies (refs, boxes), nearest neighbours, the packed keep / merge flags
+  // and their scan, subtree leaf counts, leaf positions in depth-first order
+  int32_t *pl_ref[2] = {nullptr, nullptr};
+  float *pl_box[2] = {nullptr, nullptr};
+  int32_t *pl_nn = nullptr;
+  unsigned long long *pl_flag = nullptr, *pl_scan = nullptr;
+  int32_t *pl_cnt = nullptr, *pl_pos = nullptr, *pl_parent_leaf = nullptr;
+  uint32_t *pl_state = nullptr;  // [0] clusters in the array, [1] nodes created so far
+  void *pl_scan_tmp = nullptr;
+  size_t pl_scan_tmp_bytes = 0;
 };
 
 __device__ __forceinline__ uint32_t ordered(float f) {
@@ -188,6 +201,170 @@ __global__ void k_radix_tree(const unsigned long long *keys, int n, int32_t *chi
   if (leaf_l) parent_leaf[gamma] = i; else parent_int[gamma] = i;
   if (leaf_r) parent_leaf[gamma + 1] = i; else parent_int[gamma + 1] = i;
   if (i == 0) parent_int[0] = -1;
+}
+
+// ---- pass 3b (round 5): the same arrays by parallel locally-ordered clustering --------------------------------
+// Karras' tree splits a range where the Morton keys' common prefix ends — the middle of an octree cell, wherever the
+// triangles are; the 4-wide tree collapsed from it walks 12-20 % slower than the host's SAH tree (17-18 % more
+// expected node visits by the surface-area metric, scripts/experiments/ploc_proto.cpp).  PLOC (Meister & Bittner,
+// "Parallel Locally-Ordered Clustering for Bounding Volume Hierarchy Construction", 2018) builds the tree bottom-up
+// over the same Morton order: every cluster of the current array looks `radius` places to either side for the
+// neighbour whose union with it has the smallest surface area; two clusters that choose each other merge into a new
+// node, which takes the lower one's place; the array is compacted in order; repeat until one cluster is left.  On
+// the project's meshes the metric comes within 1 % (suzanne) and 9 % (96.8k triangles) of the host tree's.
+// One iteration = nearest-neighbour kernel, flag kernel, one scan (survivors and merges in one 64-bit word), compact
+// kernel; the cluster count stays on the device and is read back every fourth iteration to shrink the launches.
+// Determinism: ties go to the lower index, node ids come from the scan (the k-th merge of the build is node
+// n - 2 - k, so the last one — the root — is node 0, as the rest of the pipeline expects), nothing depends on timing.
+// A PLOC node covers clusters that were neighbours in the array, not a contiguous range of the Morton order, and
+// the image's leaves are ranges of the triangle records: the leaves are therefore renumbered in depth-first order
+// afterwards (k_ploc_count, k_ploc_place, k_ploc_relabel) and `vals` becomes that order.
+__device__ __forceinline__ float union_area(const float *a, const float *b) {
+  const float dx = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), dy = fmaxf(a[4], b[4]) - fminf(a[1], b[1]),
+              dz = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+  return dx * dy + dy * dz + dz * dx;
+}
+__global__ void k_ploc_init(int n, const uint32_t *vals, const float *pbox, int32_t *ref, float *box, uint32_t *state) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) {
+    state[0] = (uint32_t)n;
+    state[1] = 0u;
+  }
+  if (j >= n) return;
+  ref[j] = j | kLeafBit;
+  for (int k = 0; k < 6; ++k) box[(size_t)j * 6 + k] = pbox[(size_t)vals[j] * 6 + k];
+}
+__global__ void k_ploc_nn(const uint32_t *state, int radius, const float *box, int32_t *nn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = (int)state[0];
+  if (i >= m || m < 2) return;  // (the host's bound on the array may lag behind: one cluster left = nothing to do)
+  float me[6];
+  for (int k = 0; k < 6; ++k) me[k] = box[(size_t)i * 6 + k];
+  float best = INFINITY;
+  int bj = i > 0 ? i - 1 : i + 1;  // (boxes with NaN or inf areas: still a neighbour; m >= 2 here)
+  const int j0 = max(i - radius, 0), j1 = min(i + radius, m - 1);
+  for (int j = j0; j <= j1; ++j) {
+    if (j == i) continue;
+    const float a = union_area(me, box + (size_t)j * 6);
+    if (a < best) {  // ties: the lower index
+      best = a;
+      bj = j;
+    }
+  }
+  nn[i] = bj;
+}
+// low word: this slot survives (everything but the higher cluster of a merging pair); high word: this slot is the
+// lower cluster of a merging pair (a node is created in its place).  Slots beyond the array are zero for the scan.
+__global__ void k_ploc_flags(int bound, const uint32_t *state, const int32_t *nn, unsigned long long *flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bound) return;
+  const int m = (int)state[0];
+  unsigned long long f = 0ull;
+  if (m < 2) {  // the tree is complete (the host's bound lags behind the device's count): the cluster stays, no merge
+    f = i < m ? 1ull : 0ull;
+  } else if (i < m) {
+    const int j = nn[i];
+    const bool mutual = nn[j] == i;
+    f = (mutual && i > j) ? 0ull : 1ull;
+    if (mutual && i < j) f |= 1ull << 32;
+  }
+  flag[i] = f;
+}
+__global__ void k_ploc_compact(int n, int bound, uint32_t *state_next, const uint32_t *state, const int32_t *nn,
+                               const unsigned long long *flag, const unsigned long long *scan, const int32_t *ref,
+                               const float *box, int32_t *ref_out, float *box_out, int32_t *child_l, int32_t *child_r,
+                               int32_t *parent_int, int32_t *parent_leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = (int)state[0];
+  if (i >= bound || i >= m) return;
+  const unsigned long long f = flag[i], sc = scan[i];
+  const uint32_t pos = (uint32_t)sc, rank = (uint32_t)(sc >> 32);
+  if (i == m - 1) {  // the totals: what the next iteration works on
+    state_next[0] = pos + (uint32_t)(f & 1ull);
+    state_next[1] = state[1] + rank + (uint32_t)(f >> 32);
+  }
+  if (!(f & 1ull)) return;
+  float b[6];
+  for (int k = 0; k < 6; ++k) b[k] = box[(size_t)i * 6 + k];
+  int32_t r = ref[i];
+  if (f >> 32) {
+    const int j = nn[i];
+    const int32_t id = (n - 2) - (int32_t)(state[1] + rank);
+    const int32_t rl = r, rr = ref[j];
+    child_l[id] = rl;
+    child_r[id] = rr;
+    if (rl < 0) parent_leaf[rl & 0x7fffffff] = id; else parent_int[rl] = id;
+    if (rr < 0) parent_leaf[rr & 0x7fffffff] = id; else parent_int[rr] = id;
+    const float *o = box + (size_t)j * 6;
+    for (int k = 0; k < 3; ++k) {
+      b[k] = fminf(b[k], o[k]);
+      b[3 + k] = fmaxf(b[3 + k], o[3 + k]);
+    }
+    r = id;
+  }
+  ref_out[pos] = r;
+  for (int k = 0; k < 6; ++k) box_out[(size_t)pos * 6 + k] = b[k];
+}
+// leaves under every node (bottom-up, the second arrival at a node finishes it: the pattern of k_refit)
+__global__ void k_ploc_count(int n, const int32_t *child_l, const int32_t *child_r, const int32_t *parent_int,
+                             const int32_t *parent_leaf, int32_t *cnt, uint32_t *flags) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  int node = parent_leaf[p];
+  while (node >= 0) {
+    __threadfence();
+    const uint32_t old = atomicAdd(&flags[node], 1u);
+    if (old == 0u) return;
+    __threadfence();
+    int c = 0;
+    for (const int32_t ch : {child_l[node], child_r[node]})
+      c += ch < 0 ? 1 : __hip_atomic_load(cnt + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cnt + node, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    node = parent_int[node];
+  }
+}
+// depth-first position of the first leaf under `ref` (left child first): the leaves to the left of the path to the root
+__device__ __forceinline__ int ploc_first(int32_t ref, int32_t parent, const int32_t *child_l, const int32_t *parent_int,
+                                          const int32_t *cnt) {
+  int pos = 0;
+  int32_t cur = ref, par = parent;
+  while (par >= 0) {
+    const int32_t l = child_l[par];
+    if (l != cur) pos += l < 0 ? 1 : cnt[l];
+    cur = par;
+    par = parent_int[par];
+  }
+  return pos;
+}
+__global__ void k_ploc_place(int n, const int32_t *child_l, const int32_t *parent_int, const int32_t *parent_leaf,
+                             const int32_t *cnt, const uint32_t *vals, uint32_t *vals_out, int32_t *pos, int32_t *first,
+                             int32_t *last) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * n - 1) return;
+  if (t < n) {  // leaf at Morton position t
+    const int q = ploc_first(t | kLeafBit, parent_leaf[t], child_l, parent_int, cnt);
+    pos[t] = q;
+    vals_out[q] = vals[t];
+  } else {  // inner node
+    const int id = t - n;
+    const int q = ploc_first(id, parent_int[id], child_l, parent_int, cnt);
+    first[id] = q;
+    last[id] = q + cnt[id] - 1;
+  }
+}
+// leaf references and the leaves' parents in the new numbering
+__global__ void k_ploc_relabel(int n, const int32_t *pos, const int32_t *parent_leaf_old, int32_t *child_l, int32_t *child_r,
+                               int32_t *parent_leaf) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * n - 1) return;
+  if (t < n) {
+    parent_leaf[pos[t]] = parent_leaf_old[t];
+  } else {
+    const int id = t - n;
+    const int32_t l = child_l[id], r = child_r[id];
+    if (l < 0) child_l[id] = pos[l & 0x7fffffff] | kLeafBit;
+    if (r < 0) child_r[id] = pos[r & 0x7fffffff] | kLeafBit;
+  }
 }
 
 // ---- pass 4: bottom-up boxes, emitted-subtree sizes, near-child-first bit ------------------
@@ -461,7 +638,7 @@ __global__ void k_b4_records(int nt, const uint32_t *vals, const double *tri, co
 
 // what the walk's termination and addressing rest on (validate_bvh4_image of rtow_bvh4.h): child links point to
 // LATER nodes, leaves stay inside the record section
-__global__ void k_b4_validate(const unsigned char *blob, int n4, int half, int nt, uint32_t *err) {
+__global__ void k_b4_validate(const unsigned char *blob, int n4, int half, int nt, uint32_t *seen, uint32_t *err) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const uint32_t *w = reinterpret_cast<const uint32_t *>(blob + (size_t)i * (half ? 64u : 128u) + (half ? 48u : 96u));
@@ -472,11 +649,22 @@ __global__ void k_b4_validate(const unsigned char *blob, int n4, int half, int n
     if (ok && (r & kB4RefLeaf)) {
       const uint32_t f = (r & (kB4RefLeaf - 1u)) >> 2, n = (r & 3u) + 1u;
       ok = f + n <= (uint32_t)nt;
+      if (ok)
+        for (uint32_t k = 0; k < n; ++k) atomicAdd(&seen[f + k], 1u);  // (checked by k_b4_validate_seen)
     } else if (ok) {
       ok = (int)r > i && (int)r < n4;
+      if (ok) atomicAdd(&seen[nt + r], 1u);  // every node but the root is the child of exactly one node
     }
     if (!ok) atomicOr(err, 8u);
   }
+}
+// ... and every triangle record belongs to exactly one leaf, every node but the root to exactly one parent: a collapse
+// that dropped or doubled a subtree would otherwise render a mesh with holes (or test triangles twice) without an error
+__global__ void k_b4_validate_seen(const uint32_t *seen, int nt, int n4, uint32_t *err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nt + n4) return;
+  const uint32_t want = i == nt ? 0u : 1u;  // (seen[nt + 0] is the root)
+  if (seen[i] != want) atomicOr(err, 8u);
 }
 
 void release(Scratch *s) {
@@ -484,7 +672,9 @@ void release(Scratch *s) {
   void *ptrs[] = {s->pbox,     s->pbox64,  s->keys_a,     s->keys_b,      s->vals_a, s->vals_b, s->child_l,
                   s->child_r,  s->first,   s->last,       s->parent_int,  s->parent_leaf,
                   s->ibox,     s->size,    s->flags,      s->glob,        s->sort_tmp,
-                  s->b4_src,   s->b4_child, s->b4_cw,     s->b4_cnt,      s->b4_pos, s->scan_tmp};
+                  s->b4_src,   s->b4_child, s->b4_cw,     s->b4_cnt,      s->b4_pos, s->scan_tmp, s->b4_seen,
+                  s->pl_ref[0], s->pl_ref[1], s->pl_box[0], s->pl_box[1], s->pl_nn, s->pl_flag, s->pl_scan,
+                  s->pl_cnt,   s->pl_pos,  s->pl_parent_leaf, s->pl_state, s->pl_scan_tmp};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -500,9 +690,10 @@ bool dev_alloc(T *&p, size_t count) {
 // Phase 1: builds the tree in scratch memory.  Returns 0 and the number of node records the
 // image will hold (without the END record).  `*handle` is the scratch: NULL on the first call,
 // reused (and grown when needed) by later builds, released with lbvh_release.
+// `ploc_radius`: > 0 = PLOC with that search radius (pass 3b), 0 = Karras' radix tree (pass 3).
 int lbvh_build(const double *sph, const double *sph_r, const double *mov, const double *tri, int ns, int nm,
                int nt, double time0, double time1, const double cam_origin[3], int leaf_max, void *stream,
-               void **handle, int *n_nodes) {
+               void **handle, int *n_nodes, int ploc_radius) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int n = ns + nm + nt;
   if (n <= 0 || leaf_max < 1 || leaf_max > 7) return 1;
@@ -547,9 +738,72 @@ int lbvh_build(const double *sph, const double *sph_r, const double *mov, const 
     good = rocprim::radix_sort_pairs(s->sort_tmp, tmp_bytes, s->keys_a, s->keys_b, s->vals_a, s->vals_b, (size_t)n, 0u, 63u, st) == hipSuccess;
   }
   int32_t root_size = 1;
-  if (good && n > 1) {
+  if (good && n > 2 && ploc_radius > 0) {
+    const size_t cap = (size_t)s->capacity;
+    if (!s->pl_state) {
+      bool ok = dev_alloc(s->pl_ref[0], cap) && dev_alloc(s->pl_ref[1], cap) && dev_alloc(s->pl_box[0], cap * 6) &&
+                dev_alloc(s->pl_box[1], cap * 6) && dev_alloc(s->pl_nn, cap) && dev_alloc(s->pl_flag, cap) &&
+                dev_alloc(s->pl_scan, cap) && dev_alloc(s->pl_cnt, cap) && dev_alloc(s->pl_pos, cap) &&
+                dev_alloc(s->pl_parent_leaf, cap) && dev_alloc(s->pl_state, 4);
+      if (ok)
+        ok = rocprim::exclusive_scan(nullptr, s->pl_scan_tmp_bytes, s->pl_flag, s->pl_scan, 0ull, cap,
+                                     rocprim::plus<unsigned long long>(), st) == hipSuccess &&
+             hipMalloc(&s->pl_scan_tmp, s->pl_scan_tmp_bytes ? s->pl_scan_tmp_bytes : 16) == hipSuccess;
+      if (!ok) return 2;
+    }
+    hipLaunchKernelGGL(k_ploc_init, dim3(G), dim3(B), 0, st, n, s->vals_b, s->pbox, s->pl_ref[0], s->pl_box[0], s->pl_state);
+    good = hipMemsetAsync(s->parent_int, 0xff, sizeof(int32_t), st) == hipSuccess;  // the root (node 0) has no parent
+    int bound = n, cur = 0, it = 0;  // bound: clusters the array can still hold (>= the device's count)
+    // state[0..1] = (clusters, nodes created) of the array being read; the compact kernel writes the next pair to
+    // state[2..3]; the two halves swap roles every iteration
+    while (good && bound > 1) {
+      uint32_t *st_in = s->pl_state + 2 * (it & 1), *st_out = s->pl_state + 2 * ((it + 1) & 1);
+      const int Gb = (bound + B - 1) / B;
+      hipLaunchKernelGGL(k_ploc_nn, dim3(Gb), dim3(B), 0, st, st_in, ploc_radius, s->pl_box[cur], s->pl_nn);
+      hipLaunchKernelGGL(k_ploc_flags, dim3(Gb), dim3(B), 0, st, bound, st_in, s->pl_nn, s->pl_flag);
+      size_t tb = s->pl_scan_tmp_bytes;
+      good = rocprim::exclusive_scan(s->pl_scan_tmp, tb, s->pl_flag, s->pl_scan, 0ull, (size_t)bound,
+                                     rocprim::plus<unsigned long long>(), st) == hipSuccess;
+      if (!good) break;
+      hipLaunchKernelGGL(k_ploc_compact, dim3(Gb), dim3(B), 0, st, n, bound, st_out, st_in, s->pl_nn, s->pl_flag, s->pl_scan,
+                         s->pl_ref[cur], s->pl_box[cur], s->pl_ref[cur ^ 1], s->pl_box[cur ^ 1], s->child_l, s->child_r,
+                         s->parent_int, s->pl_parent_leaf);
+      cur ^= 1;
+      ++it;
+      // every iteration merges at least the closest pair of the array
+      bound -= 1;
+      if ((it & 3) == 0 || bound <= 1) {
+        uint32_t m_now = 0;
+        good = hipMemcpyAsync(&m_now, st_out, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+        if (good && (m_now < 1u || (int)m_now > bound + 1)) return 3;
+        bound = (int)m_now;
+      }
+      if (it > 4 * n) return 3;  // (cannot happen)
+    }
+    if (good) {  // one cluster left, n - 1 nodes created: anything else is an incomplete tree, never handed on
+      uint32_t fin[2] = {0u, 0u};
+      good = hipMemcpyAsync(fin, s->pl_state + 2 * (it & 1), 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+      if (good && (fin[0] != 1u || fin[1] != (uint32_t)(n - 1))) return 3;
+    }
+    if (good) {
+      // leaves in depth-first order: counts, positions, the new `vals`, leaf references
+      const int G2 = (2 * n - 1 + B - 1) / B;
+      hipLaunchKernelGGL(k_ploc_count, dim3(G), dim3(B), 0, st, n, s->child_l, s->child_r, s->parent_int, s->pl_parent_leaf,
+                         s->pl_cnt, s->flags);
+      hipLaunchKernelGGL(k_ploc_place, dim3(G2), dim3(B), 0, st, n, s->child_l, s->parent_int, s->pl_parent_leaf, s->pl_cnt,
+                         s->vals_b, s->vals_a, s->pl_pos, s->first, s->last);
+      hipLaunchKernelGGL(k_ploc_relabel, dim3(G2), dim3(B), 0, st, n, s->pl_pos, s->pl_parent_leaf, s->child_l, s->child_r,
+                         s->parent_leaf);
+      std::swap(s->vals_a, s->vals_b);  // vals_b is what everything downstream reads: now the depth-first order
+      good = hipMemsetAsync(s->flags, 0, ni * sizeof(uint32_t), st) == hipSuccess;  // (k_refit's arrival counters)
+    }
+  } else if (good && n > 1) {
     hipLaunchKernelGGL(k_radix_tree, dim3(G), dim3(B), 0, st, s->keys_b, n, s->child_l, s->child_r, s->first,
                        s->last, s->parent_int, s->parent_leaf);
+  }
+  if (good && n > 1) {
     hipLaunchKernelGGL(k_refit, dim3(G), dim3(B), 0, st, n, leaf_max, s->vals_b, s->pbox, s->child_l, s->child_r,
                        s->first, s->last, s->parent_int, s->parent_leaf, (float)cam_origin[0],
                        (float)cam_origin[1], (float)cam_origin[2], s->ibox, s->size, s->flags);
@@ -594,7 +848,7 @@ int lbvh_bvh4_collapse(void *handle, int leaf_max, void *stream, int *n_nodes, i
   if (!s->b4_src) {
     size_t tb = 0;
     bool ok = dev_alloc(s->b4_src, cap) && dev_alloc(s->b4_child, cap * 4) && dev_alloc(s->b4_cw, cap * 4) &&
-              dev_alloc(s->b4_cnt, cap) && dev_alloc(s->b4_pos, cap) &&
+              dev_alloc(s->b4_cnt, cap) && dev_alloc(s->b4_pos, cap) && dev_alloc(s->b4_seen, cap * 2) &&
               rocprim::exclusive_scan(nullptr, tb, s->b4_cnt, s->b4_pos, 0u, cap, rocprim::plus<uint32_t>(), st) == hipSuccess &&
               hipMalloc(&s->scan_tmp, tb ? tb : 16) == hipSuccess;
     if (!ok) return 2;
@@ -656,7 +910,11 @@ int lbvh_bvh4_emit(void *handle, unsigned char *blob_dev, int half, const double
                      map_c[0], map_c[1], map_c[2], map_s[0], map_s[1], map_s[2]);
   hipLaunchKernelGGL(k_b4_records, dim3((n + B - 1) / B), dim3(B), 0, st, n, s->vals_b, tri, prim_mat, blob_dev, off_tri,
                      off_pmat);
-  hipLaunchKernelGGL(k_b4_validate, dim3((n4 + B - 1) / B), dim3(B), 0, st, blob_dev, n4, half, n, s->glob + 7);
+  // (the arrival counters of the collapse are free again: [0, n) triangles, [n, n + n4) nodes; n + n4 <= 2 * capacity)
+  uint32_t *seen = s->b4_seen;
+  if (hipMemsetAsync(seen, 0, ((size_t)n + (size_t)n4) * sizeof(uint32_t), st) != hipSuccess) return 3;
+  hipLaunchKernelGGL(k_b4_validate, dim3((n4 + B - 1) / B), dim3(B), 0, st, blob_dev, n4, half, n, seen, s->glob + 7);
+  hipLaunchKernelGGL(k_b4_validate_seen, dim3((n + n4 + B - 1) / B), dim3(B), 0, st, seen, n, n4, s->glob + 7);
   uint32_t err = 1;
   const bool good = hipMemcpyAsync(&err, s->glob + 7, sizeof err, hipMemcpyDeviceToHost, st) == hipSuccess &&
                     hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;

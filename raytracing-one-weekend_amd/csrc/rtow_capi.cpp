@@ -220,7 +220,7 @@ double now_ms() {
 namespace rtow {  // csrc/rtow_build.hip
 int lbvh_build(const double *sph, const double *sph_r, const double *mov, const double *tri, int ns, int nm,
                int nt, double time0, double time1, const double cam_origin[3], int leaf_max, void *stream,
-               void **handle, int *n_nodes);
+               void **handle, int *n_nodes, int ploc_radius);
 int lbvh_emit(void *handle, int leaf_max, unsigned char *blob_dev, uint32_t off_ids, int n_nodes, void *stream);
 int lbvh_bvh4_collapse(void *handle, int leaf_max, void *stream, int *n_nodes, int *depth, float root_box[6]);
 int lbvh_bvh4_emit(void *handle, unsigned char *blob_dev, int half, const double map_c[3], const double map_s[3],
@@ -277,6 +277,8 @@ struct Knobs {
                                   //   pixel, like the strict build).  5 / 10 / 20 / 25: 10.88 / 11.18 / 10.22 / 9.55 Gsamples/s on C2
   int sched_chunk_mesh = 16;      //   ... for a scene of triangles only (its walks are longer and resumable: fewer, longer items;
                                   //   4 / 8 / 16 / 32 samples: 4.60 / 4.64 / 4.69 / 4.68 Gsamples/s on C4, 2.29 / 2.30 / 2.32 / 2.32 on C5)
+  int ploc_radius = -1;           // RTOW_PLOC_RADIUS: device builder: search radius of the PLOC pass (csrc/rtow_build.hip, round 5);
+                                  //   0 = Karras' radix tree (rounds 1-4); -1 = default: 16 up to 16,384 primitives, 8 above
   bool no_spec = false;           // RTOW_NO_SPEC: always the generic GRID kernel (A/B against the scene-class specialisations)
   int tail_bound = 0;             // RTOW_TAIL_BOUND (tests only): trips of the end-of-launch protocol before a wave gives up
                                   //   its samples (0 = the structural bound); a small value forces the RTOW_EHIP path
@@ -324,6 +326,7 @@ struct Knobs {
     sched_chunk_mesh = std::min(std::max(geti("RTOW_SCHED_CHUNK_MESH", 16), 0), 4096);
     tail_bound = std::max(geti("RTOW_TAIL_BOUND", 0), 0);
     no_spec = std::getenv("RTOW_NO_SPEC") != nullptr;
+    if (const char *e = std::getenv("RTOW_PLOC_RADIUS")) ploc_radius = std::min(std::max(std::atoi(e), 0), 64);
   }
 };
 
@@ -354,7 +357,8 @@ struct rtow_ctx {
   bool have_grid = false;
   uint32_t blob_bytes = 0;
   long long bvh_nodes = 0;
-  int builder = RTOW_BUILDER_HOST_SAH;
+  int builder = RTOW_BUILDER_HOST_SAH;      // the builder of the upload in progress / of the resident images
+  int builder_req = RTOW_BUILDER_AUTO;      // what the caller asked for (rtow_ctx_set_builder, RTOW_BUILDER)
   void *lbvh_scratch = nullptr;  // device builder's buffers, kept across uploads
   void *grid_scratch = nullptr;
   rtow_build_info_t build_info{};
@@ -392,7 +396,10 @@ struct rtow_ctx {
 };
 
 // BVH4: stack entries per lane (4 B x 1024 lanes each) an image staged whole must leave room for (RTOW_BVH4_STACK_K)
-static uint32_t bvh4_min_stack(const rtow_ctx *c) { return c->knobs.bvh4_stack_k > 0 ? (uint32_t)c->knobs.bvh4_stack_k : 8u; }
+// (round 5: 6, was 8 — suzanne's host tree walks at the same rate with 8, 7 and 6 entries per lane in LDS, and two more
+// entry levels are 8 KB = 64 nodes of room for a mesh near the limit: the device-built suzanne tree, 276 nodes against
+// the host's 261, is staged whole with 7)
+static uint32_t bvh4_min_stack(const rtow_ctx *c) { return c->knobs.bvh4_stack_k > 0 ? (uint32_t)c->knobs.bvh4_stack_k : 6u; }
 
 extern "C" {
 
@@ -416,7 +423,9 @@ static int impl_ctx_create(int device_id, rtow_ctx **out) {
   c->num_cus = prop.multiProcessorCount;
   c->knobs.read();
   if (const char *e = std::getenv("RTOW_BUILDER"))
-    c->builder = std::strcmp(e, "device") == 0 ? RTOW_BUILDER_DEVICE_LBVH : RTOW_BUILDER_HOST_SAH;
+    c->builder_req = std::strcmp(e, "device") == 0 ? RTOW_BUILDER_DEVICE_LBVH
+                     : std::strcmp(e, "auto") == 0 ? RTOW_BUILDER_AUTO : RTOW_BUILDER_HOST_SAH;
+  c->builder = c->builder_req == RTOW_BUILDER_DEVICE_LBVH ? RTOW_BUILDER_DEVICE_LBVH : RTOW_BUILDER_HOST_SAH;
   // every failure below releases what was created so far (rtow_ctx_destroy skips null handles)
   hipError_t he = hipSuccess;
   for (int i = 0; i < kEventRing && he == hipSuccess; ++i)
@@ -632,7 +641,8 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
     int n_nodes = 0;
     int brc = rtow::lbvh_build((const double *)c->sph.p, (const double *)c->sph_r.p, (const double *)c->mov.p,
                                (const double *)c->tri.p, ns, nm, nt, s->camera.t0, s->camera.t1, s->camera.origin,
-                               leaf_max, nullptr, &c->lbvh_scratch, &n_nodes);
+                               leaf_max, nullptr, &c->lbvh_scratch, &n_nodes,
+                               c->knobs.ploc_radius >= 0 ? c->knobs.ploc_radius : (ns + nm + nt <= 16384 ? 16 : 8));
     if (brc) return fail(RTOW_EHIP, "device BVH build failed (stage %d): %s", brc, hipGetErrorString(hipGetLastError()));
     if (want2) {
     rtow::layout_scene_image(n_nodes, (size_t)(ns + nm + nt), sph, mov, tri, pmat, mats_bytes, img, true);
@@ -977,9 +987,10 @@ static int validate_cfg(const rtow_config_t *cfg) {
 
 int rtow_ctx_set_builder(rtow_ctx *c, int32_t builder) {
   if (!c) return fail(RTOW_EINVAL, "ctx is NULL");
-  if (builder != RTOW_BUILDER_HOST_SAH && builder != RTOW_BUILDER_DEVICE_LBVH)
+  if (builder != RTOW_BUILDER_HOST_SAH && builder != RTOW_BUILDER_DEVICE_LBVH && builder != RTOW_BUILDER_AUTO)
     return fail(RTOW_EINVAL, "unknown builder %d", builder);
-  c->builder = builder;
+  c->builder_req = builder;
+  c->builder = builder == RTOW_BUILDER_DEVICE_LBVH ? RTOW_BUILDER_DEVICE_LBVH : RTOW_BUILDER_HOST_SAH;  // (AUTO without a config: host)
   return RTOW_OK;
 }
 
@@ -1595,6 +1606,17 @@ static int upload_for(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_
     need = kNeedBvh4;  // the 4-wide image only (the binary image is another 20 ms and 10 MB for the 96.8k-triangle mesh)
   else
     need = kNeedBvh;
+  if (c->builder_req == RTOW_BUILDER_AUTO) {
+    // AUTO (include/rtow.h): the device builder where the frame is short against the host build it saves — a big
+    // triangle mesh at a low sample count.  Measured on the 96,800-triangle mesh: host 15 ms,
+    // device 3.3 ms, the device-built tree walks 7 % slower at 2.46 Gsamples/s => break-even near 4,000 samples per
+    // triangle.
+    const long long spp_eff = (long long)(cfg->samples_per_pixel / cfg->nstreams) * cfg->nstreams;
+    const long long samples = (long long)cfg->image_width * rtow_local_rows(cfg) * spp_eff;
+    const bool device = mesh && need == kNeedBvh4 && scene->n_triangles >= 16384 &&
+                        samples < 4000ll * (long long)scene->n_triangles;
+    c->builder = device ? RTOW_BUILDER_DEVICE_LBVH : RTOW_BUILDER_HOST_SAH;
+  }
   rc = scene_upload(c, scene, need);
   if (rc == RTOW_OK && (need & kNeedGrid) && !(need & kNeedBvh) && !c->have_grid)
     rc = scene_upload(c, scene, need | kNeedBvh);  // the scene does not suit a grid: the walk falls back to the BVH

@@ -79,7 +79,7 @@ static void usage(const char *argv0) {
                "                              reference's own median-split tree and f64 box test, strict arithmetic)\n"
                "  --primitives oo|variant|world  scene model the scripts build (the reference picks at compile time;\n"
                "                              world = src/vmodel.h, spheres only)\n"
-               "  --builder host|device       BVH build: host SAH (default) or on the GPU (LBVH)\n"
+               "  --builder host|device|auto  BVH build: host SAH, on the GPU (PLOC), or (default) whichever delivers the frame sooner\n"
                "  --p6                        binary P6 output, write_color on the device\n"
                "  --general-obj               with -l: load every shape, not only the first\n"
                "  --gpus INT                  tile-split over INT devices (--device is the first), strips gathered\n"
@@ -151,7 +151,8 @@ int main(int argc, char *argv[]) {
         const std::string v = value();
         if (v == "host") opt.builder = 0;
         else if (v == "device") opt.builder = 1;
-        else throw std::runtime_error("--builder: host|device");
+        else if (v == "auto") opt.builder = 2;
+        else throw std::runtime_error("--builder: host|device|auto");
       } else if (std::strcmp(a, "--kernel") == 0) {
         const std::string v = value();
         if (v == "auto") opt.kernel = 0;

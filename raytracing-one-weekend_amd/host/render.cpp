@@ -322,7 +322,7 @@ static void render_flat(FlatScene *flat, const Config &cfg) {
   // structures this render's kernel reads are built)
   if (bi.bvh_image_bytes > 0)
     std::cerr << "BVH image: " << bi.bvh_nodes << " nodes, " << bi.bvh_image_bytes << " bytes, built on the "
-              << (bi.builder == RTOW_BUILDER_DEVICE_LBVH ? "device (LBVH)" : "host (SAH)") << " in " << bi.bvh_build_ms
+              << (bi.builder == RTOW_BUILDER_DEVICE_LBVH ? "device (PLOC)" : "host (SAH)") << " in " << bi.bvh_build_ms
               << " ms" << (bi.bvh4_nodes > 0 ? "; 4-wide image: " + std::to_string(bi.bvh4_nodes) + " nodes of " + std::to_string(bi.bvh4_node_bytes) + " bytes"
                                    : std::string()) << "\n";
   if (bi.grid_image_bytes > 0)

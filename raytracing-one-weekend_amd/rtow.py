@@ -24,7 +24,7 @@ PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_TRIANGLE = 0, 1, 2
 F64_STRICT, F64_FAST, F32 = 0, 1, 2
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BVH, KERNEL_GRID, KERNEL_BVH4, KERNEL_REFTREE = 0, 1, 2, 3, 4, 5
 MODEL_OO, MODEL_VARIANT, MODEL_WORLD = 0, 1, 2  # scene models of the host scene scripts (include/rtow.h)
-BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1
+BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH, BUILDER_AUTO = 0, 1, 2
 
 d3 = C.c_double * 3
 _pd = C.POINTER(C.c_double)
