@@ -814,8 +814,12 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
       if (max_list <= 255 && total_ids + (unsigned long long)gb.n_large < (1u << 24)) {
         const size_t ncell = (size_t)hd.n[0] * hd.n[1] * hd.n[2];
         for (int k = 0; k < 3; ++k) gimg.n[k] = hd.n[k];
+        double scale_small = 0.0;  // (the host builder's rule: rtow_grid.h build_grid_image)
+        for (int k = 0; k < 3; ++k)
+          scale_small = std::max({scale_small, std::fabs(gb.gmn[k]), std::fabs(gb.gmx[k]), std::fabs(s->camera.origin[k])});
         const uint32_t fat = rtow::grid_wants_fat_lists(nm, nt, ncell, (size_t)total_ids + (size_t)gb.n_large,
-                                                        (size_t)gb.n_large, sph, mov, tri, pmat, mats_bytes, (size_t)total_ids);
+                                                        (size_t)gb.n_large, sph, mov, tri, pmat, mats_bytes, (size_t)total_ids,
+                                                        scale_small);
         rtow::layout_grid_image(ncell, (size_t)total_ids + (size_t)gb.n_large, (size_t)gb.n_large, sph, mov, tri, pmat,
                                 mats_bytes, gimg, true, fat ? (size_t)total_ids : 0, fat ? fat : 48u);
         if ((rc = c->gblob.ensure(gimg.total_bytes))) return rc;

@@ -152,10 +152,23 @@ inline void write_grid_header(unsigned char *h, const GridHeader &hd, uint32_t n
 inline uint32_t grid_wants_fat_lists(int n_moving, int n_triangles, size_t ncell, size_t total_ids, size_t n_large,
                                      const std::vector<double> &sph, const std::vector<double> &mov,
                                      const std::vector<double> &tri, const std::vector<int32_t> &prim_mat,
-                                     const std::vector<unsigned char> &mats_bytes, size_t n_cell_ids) {
+                                     const std::vector<unsigned char> &mats_bytes, size_t n_cell_ids,
+                                     double scale_small = 0.0) {
   if (n_triangles != 0 || n_cell_ids == 0 || std::getenv("RTOW_GRID_NO_FAT")) return 0u;
-  const uint32_t stride = n_moving != 0 ? 80u : 48u;
-  if (stride == 80u && std::getenv("RTOW_GRID_NO_FAT_MOVING")) return 0u;
+  // 48-byte entries carry k = |c|^2 - r^2 for the fast builds' 8-operation test, c = |o|^2 - 2 c.o + k, whose
+  // cancellation is of the size of |o|^2 and |c|^2 in WORLD coordinates: 2^-52 * 2 scale^2 absolute, against r^2.
+  // Measured on the cover scene moved off the origin (scripts/far_origin_check.py, profiles/r05_far_origin.log): at
+  // coordinates of 1e4 the fast image differs from the strict one beyond 1e-9 in 45 % of the pixels (5e-7 per sample:
+  // invisible, but not the build's usual agreement); at the origin in none.  A scene whose small primitives (and
+  // camera) sit further out than 1,000 times its smallest sphere radius therefore takes the 80-byte entries — centre
+  // and r^2 as they are, the 12-operation test on o - c — like a scene with moving spheres.  (Rendering in the frame
+  // of the grid's centre instead keeps the 8 operations at any distance and costs 3 subtractions and a scalar-load
+  // wait per segment: -1 % on the benchmark scene; scripts/experiments/r05_fat_entries_in_grid_frame.patch.)
+  double min_r2 = INFINITY;
+  for (size_t i = 0; i < sph.size() / 4; ++i) min_r2 = std::min(min_r2, std::fabs(sph[i * 4 + 3]));
+  const bool far = scale_small * scale_small > 1e6 * min_r2;
+  const uint32_t stride = (n_moving != 0 || far) ? 80u : 48u;
+  if (stride == 80u && n_moving != 0 && std::getenv("RTOW_GRID_NO_FAT_MOVING")) return 0u;
   GridImage probe;
   layout_grid_image(ncell, total_ids, n_large, sph, mov, tri, prim_mat, mats_bytes, probe, true, n_cell_ids, stride);
   return probe.total_bytes <= 160u * 1024u ? stride : 0u;
@@ -289,8 +302,11 @@ inline void build_grid_image(const std::vector<double> &sph, const std::vector<d
 
   // fat lists: scenes of spheres only, when the image still fits LDS with them
   const size_t n_cell_ids = total_ids - large.size();
+  double scale_small = 0.0;  // how far from the origin the small primitives and the camera sit
+  for (int k = 0; k < 3; ++k)
+    scale_small = std::max({scale_small, std::fabs(gmn[k]), std::fabs(gmx[k]), std::fabs(cam_origin[k])});
   const uint32_t fat = grid_wants_fat_lists(nm, nt, (size_t)ncell, total_ids, large.size(), sph, mov, tri, prim_mat,
-                                            mats_bytes, n_cell_ids);
+                                            mats_bytes, n_cell_ids, scale_small);
   layout_grid_image((size_t)ncell, total_ids, large.size(), sph, mov, tri, prim_mat, mats_bytes, img, false,
                     fat ? n_cell_ids : 0, fat ? fat : 48u);
 

@@ -1033,9 +1033,22 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
 
 }  // namespace
 
+// The trace kernels address the dynamic LDS block from 0 (lds_read / lds_write, rtow_trace_bvh4.h): an instantiation
+// that had static LDS of its own would read the wrong bytes.  Checked once per instantiation, on the kernel that is
+// actually launched (the occupancy query below looks at one representative only).
+template <class Kern>
+static int no_static_lds(Kern k) {
+  hipFuncAttributes fa;
+  const hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k));
+  if (e != hipSuccess) return (int)e;
+  return fa.sharedSizeBytes == 0 ? 0 : (int)hipErrorInvalidValue;
+}
+
 template <bool L, bool S>
 static int launch_sm4(const TraceParams &p, int grid, int block, unsigned lds_bytes, hipStream_t st) {
   auto k = RTOW_CAT(rtow_trace4_, RTOW_SUFFIX)<L, S>;
+  static const int lds_ok = no_static_lds(k);
+  if (lds_ok != 0) return lds_ok;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1049,6 +1062,8 @@ static int launch_sm4(const TraceParams &p, int grid, int block, unsigned lds_by
 template <int K, bool L, bool S, int SPEC = 0>
 static int launch_one(const TraceParams &p, int grid, int block, unsigned lds_bytes, hipStream_t st) {
   auto k = RTOW_CAT(rtow_trace_, RTOW_SUFFIX)<K, L, S, SPEC>;
+  static const int lds_ok = no_static_lds(k);  // (one static per instantiation)
+  if (lds_ok != 0) return lds_ok;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
