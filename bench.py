@@ -100,6 +100,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--width", type=int, default=0, help="override the image width (a custom config: profiling of the "
+                                                         "streaming stress leg, --workload mesh100k --kernel brute --spp 1 --width 960)")
     ap.add_argument("--workload", choices=list(WORKLOADS), default="cover")
     ap.add_argument("--no-scaling-base", action="store_true",
                     help="N=1: skip the extra configs[2] (500 spp) measurement on this GPU")
@@ -586,9 +588,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev, timeout=__import__("datetime").timedelta(seconds=180))
 
     kind, W, aspect, spp0, DEPTH, spi, base_cfg = WORKLOADS[a.workload]
+    if a.width:
+        W, base_cfg = a.width, "custom"
     H = rtow.image_height(W, aspect)
     spp = a.spp or (spp0 if (world == 1 or kind not in ("cover", "moving")) else 500)
-    nstreams = max(1, spp // spi)
+    nstreams = max(1, spp // min(spi, spp))
     # strips of 8 rows (8x8-pixel tiles: +0.8 % over 16x4) when they deal out evenly, else 4
     tile_rows = strip_height(H, world)
     precision = {"fast": rtow.F64_FAST, "strict": rtow.F64_STRICT, "f32": rtow.F32}[a.precision]
@@ -687,7 +691,7 @@ def main():
                             + ("" if world == 1 else
                                (f", sample-split over {world} GPUs + gather of full frames" if split_samples else
                                 f", {tile_rows}-row strips over {world} GPUs + 1 RCCL gather")),
-                "baseline_config": base_cfg if (world == 1 and spp == spp0) else
+                "baseline_config": base_cfg if (world == 1 and spp == spp0 or base_cfg == "custom") else
                                    ("configs[2]" if (spp == 500 and kind == "cover") else "custom"),
                 "spp_effective": spp_eff, "samples_per_item": spi, "nstreams": nstreams,
                 "seed": SEED, "precision": a.precision,
