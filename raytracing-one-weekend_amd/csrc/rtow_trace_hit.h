@@ -132,6 +132,7 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3d o,
     cdptr g = (cdptr)sc.tri;
     const int n = sc.n_tri;
     const int base = sc.n_sph + sc.n_mov;
+#ifdef RTOW_STREAM_NO_PREFETCH  // (rounds 1-4: every record is loaded, waited for and tested in turn)
 #pragma unroll 2
     for (int i = 0; i < n; ++i) {
       V3d A = {g[12 * i + 0], g[12 * i + 1], g[12 * i + 2]};
@@ -140,6 +141,29 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3d o,
       V3d nn = {g[12 * i + 9], g[12 * i + 10], g[12 * i + 11]};
       triangle_test<double>(o, d, A, e1, e2, nn, base + i, tmin, best);
     }
+#else
+    // Software-pipelined (round 5): the scalar loads of record i + 1 are issued BEFORE record i is tested, so their
+    // latency runs under the ~25 binary64 instructions of a test instead of in front of them.  The compiler does not
+    // do this by itself — the test's early-out is a branch, and it waits (s_waitcnt lgkmcnt(0)) right behind every
+    // record's loads: the PMC pass of the 96,800-triangle streaming stress showed VALU issue utilisation 0.28 with
+    // 57 % of the wave cycles waiting (profiles/r05_pmc_stream.json).  Same operations on the same operands: the
+    // image cannot change.  (The last iteration reloads record n - 1: in bounds, unused.)
+    if (n > 0) {
+      double r[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) r[k] = g[k];
+      for (int i = 0; i < n; ++i) {
+        const int j = i + 1 < n ? i + 1 : i;
+        double q[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) q[k] = g[12 * j + k];
+        triangle_test<double>(o, d, V3d{r[0], r[1], r[2]}, V3d{r[3], r[4], r[5]}, V3d{r[6], r[7], r[8]},
+                              V3d{r[9], r[10], r[11]}, base + i, tmin, best);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) r[k] = q[k];
+      }
+    }
+#endif
   }
   return best;
 }
