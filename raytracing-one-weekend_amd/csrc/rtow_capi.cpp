@@ -346,9 +346,10 @@ struct rtow_ctx {
   rtow::DevCamera cam{};
   int n_prims = 0;
   // scene buffers
-  DevBuf sph, sph_r, mov, tri, prim_mat, mats, blob, cam_dev, gblob;
+  DevBuf sph, sph_r, mov, tri, tri16, prim_mat, mats, blob, cam_dev, gblob;
   DevBuf blob4;                        // 4-wide BVH image (triangle meshes)
   bool have_bvh4 = false;
+  bool have_tri16 = false;             // the STREAM kernel's 128-byte-stride triangle records are resident
   int bvh4_depth = 0;
   DevBuf blob32, gblob32, cam32_dev;  // the f32 build's scene images and camera
   rtow::DevScene ds32{};               // ds with the f32 images' pointers and offsets
@@ -452,7 +453,7 @@ void rtow_ctx_destroy(rtow_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
+  for (DevBuf *b : {&c->sph, &c->sph_r, &c->mov, &c->tri, &c->tri16, &c->prim_mat, &c->mats, &c->blob, &c->cam_dev, &c->gblob,
                     &c->blob32, &c->gblob32, &c->cam32_dev, &c->blob4,
                     &c->partials, &c->stack, &c->counters, &c->spill, &c->out, &c->out8, &c->rtree, &c->counters_init,
                     &c->dropped})
@@ -625,6 +626,16 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
   if ((rc = upload(c->sph, sph)) || (rc = upload(c->sph_r, sph_r)) || (rc = upload(c->mov, mov)) ||
       (rc = upload(c->tri, tri)) || (rc = upload(c->prim_mat, pmat)) || (rc = upload(c->mats, mats)))
     return rc;
+  // the STREAM kernel's copy of the triangle records at a 128-byte stride (rtow_device.h): for the uploads that may be
+  // followed by a STREAM render of triangles — everything (rtow_scene_upload) or nothing but the records (a render
+  // that asked for the STREAM / reference-tree kernels)
+  c->have_tri16 = false;
+  if (nt > 0 && (need == kNeedAll || need == 0u)) {
+    std::vector<double> tri16((size_t)nt * 16, 0.0);
+    for (int i = 0; i < nt; ++i) std::memcpy(&tri16[(size_t)i * 16], &tri[(size_t)i * 12], 12 * sizeof(double));
+    if ((rc = upload(c->tri16, tri16))) return rc;
+    c->have_tri16 = true;
+  }
   bool leaf_direct = false;
   std::vector<double> tri_img;    // leaf-ordered copies (triangle meshes, host builder)
   std::vector<int32_t> pmat_img;
@@ -860,6 +871,7 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
   ds.sph_r = (const double *)c->sph_r.p;
   ds.mov = (const double *)c->mov.p;
   ds.tri = (const double *)c->tri.p;
+  ds.tri16 = c->have_tri16 ? (const double *)c->tri16.p : nullptr;
   ds.prim_mat = (const int32_t *)c->prim_mat.p;
   ds.mats = (const rtow::DevMaterial *)c->mats.p;
   ds.n_sph = ns;
@@ -1225,6 +1237,9 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
              : (c->have_grid && c->ds.n_tri == 0) ? RTOW_KERNEL_GRID
              : bvh4_ok ? RTOW_KERNEL_BVH4 : RTOW_KERNEL_BVH;
   if (kernel == RTOW_KERNEL_GRID && !c->have_grid) kernel = RTOW_KERNEL_BVH;  // scene not suited to a grid
+  if (kernel == RTOW_KERNEL_BRUTE && c->ds.n_tri > 0 && !c->have_tri16)
+    return fail(RTOW_ENOSCENE, "the resident scene was uploaded for another kernel (the STREAM kernel's triangle records are "
+                               "missing): call rtow_scene_upload");
   if (kernel == RTOW_KERNEL_BVH4 && !bvh4_ok) kernel = RTOW_KERNEL_BVH;
   if ((kernel == RTOW_KERNEL_BVH && !(c->built & kNeedBvh)) || (f32 && !(c->built & kNeedF32)))
     return fail(RTOW_ENOSCENE, "the resident scene was uploaded by rtow_render for another kernel / precision: "

@@ -35,6 +35,9 @@ struct DevScene {
   const double *sph_r;     // [n_sph]     r (sign decides front_facing)
   const double *mov;       // [n_mov][8]  c0xyz (c1-c0)xyz copysign(r*r, r) r
   const double *tri;       // [n_tri][12] a e1 e2 n=e1×e2
+  const double *tri16;     // the same records at a stride of 16 doubles (128 B: a record is one 64-byte and one 32-byte
+                           // aligned scalar load for the STREAM kernel; at 96 B it arrived in five or six pieces); NULL
+                           // unless rtow_scene_upload built everything or the render asked for the STREAM kernel
   const int32_t *prim_mat; // [n_prims]   material index by class-major id
   const DevMaterial *mats;
   int32_t n_sph, n_mov, n_tri, n_mats;

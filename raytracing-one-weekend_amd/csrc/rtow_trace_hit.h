@@ -129,41 +129,36 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3d o,
     }
   }
   {
-    cdptr g = (cdptr)sc.tri;
+    // Triangles, software-pipelined over records at a 128-byte stride (round 5).  The PMC pass of the 96,800-triangle
+    // streaming stress (profiles/r05_pmc_stream_before.json) showed VALU issue utilisation 0.28 and the CU's scalar pipe — one
+    // for four SIMDs — 72 % busy: a 96-byte record at a 96-byte stride is only 32-byte aligned, so it arrived as five
+    // or six scalar loads, and the compiler waited (s_waitcnt lgkmcnt(0)) right behind every record's loads because
+    // the test's early-out is a branch.  Now a record is ONE x16 and ONE x8 load, and the loads of the next record are
+    // issued before the current one is tested (two register sets, alternating: no copies).  Same operations on the
+    // same operands in the same order: the image cannot change.
+    cdptr g = (cdptr)sc.tri16;
     const int n = sc.n_tri;
     const int base = sc.n_sph + sc.n_mov;
-#ifdef RTOW_STREAM_NO_PREFETCH  // (rounds 1-4: every record is loaded, waited for and tested in turn)
-#pragma unroll 2
-    for (int i = 0; i < n; ++i) {
-      V3d A = {g[12 * i + 0], g[12 * i + 1], g[12 * i + 2]};
-      V3d e1 = {g[12 * i + 3], g[12 * i + 4], g[12 * i + 5]};
-      V3d e2 = {g[12 * i + 6], g[12 * i + 7], g[12 * i + 8]};
-      V3d nn = {g[12 * i + 9], g[12 * i + 10], g[12 * i + 11]};
-      triangle_test<double>(o, d, A, e1, e2, nn, base + i, tmin, best);
-    }
-#else
-    // Software-pipelined (round 5): the scalar loads of record i + 1 are issued BEFORE record i is tested, so their
-    // latency runs under the ~25 binary64 instructions of a test instead of in front of them.  The compiler does not
-    // do this by itself — the test's early-out is a branch, and it waits (s_waitcnt lgkmcnt(0)) right behind every
-    // record's loads: the PMC pass of the 96,800-triangle streaming stress showed VALU issue utilisation 0.28 with
-    // 57 % of the wave cycles waiting (profiles/r05_pmc_stream.json).  Same operations on the same operands: the
-    // image cannot change.  (The last iteration reloads record n - 1: in bounds, unused.)
     if (n > 0) {
-      double r[12];
+      double a[12], b[12];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) r[k] = g[k];
-      for (int i = 0; i < n; ++i) {
-        const int j = i + 1 < n ? i + 1 : i;
-        double q[12];
+      for (int k = 0; k < 12; ++k) a[k] = g[k];
+      int i = 0;
+      for (; i + 1 < n; i += 2) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) q[k] = g[12 * j + k];
-        triangle_test<double>(o, d, V3d{r[0], r[1], r[2]}, V3d{r[3], r[4], r[5]}, V3d{r[6], r[7], r[8]},
-                              V3d{r[9], r[10], r[11]}, base + i, tmin, best);
+        for (int k = 0; k < 12; ++k) b[k] = g[16 * (i + 1) + k];
+        triangle_test<double>(o, d, V3d{a[0], a[1], a[2]}, V3d{a[3], a[4], a[5]}, V3d{a[6], a[7], a[8]},
+                              V3d{a[9], a[10], a[11]}, base + i, tmin, best);
+        const int j = i + 2 < n ? i + 2 : n - 1;  // (the last round reloads a record it does not use: in bounds)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) r[k] = q[k];
+        for (int k = 0; k < 12; ++k) a[k] = g[16 * j + k];
+        triangle_test<double>(o, d, V3d{b[0], b[1], b[2]}, V3d{b[3], b[4], b[5]}, V3d{b[6], b[7], b[8]},
+                              V3d{b[9], b[10], b[11]}, base + i + 1, tmin, best);
       }
+      if (i < n)
+        triangle_test<double>(o, d, V3d{a[0], a[1], a[2]}, V3d{a[3], a[4], a[5]}, V3d{a[6], a[7], a[8]},
+                              V3d{a[9], a[10], a[11]}, base + i, tmin, best);
     }
-#endif
   }
   return best;
 }
