@@ -130,8 +130,8 @@ __device__ __forceinline__ Closest closest_hit_stream(const DevScene &sc, V3d o,
   }
   {
     // Triangles, software-pipelined over records at a 128-byte stride (round 5).  The PMC pass of the 96,800-triangle
-    // streaming stress (profiles/r05_pmc_stream_before.json) showed VALU issue utilisation 0.28 and the CU's scalar pipe — one
-    // for four SIMDs — 72 % busy: a 96-byte record at a 96-byte stride is only 32-byte aligned, so it arrived as five
+    // streaming stress (profiles/r05_pmc_stream_before.json) showed VALU issue utilisation 0.28 with 57 % of the wave
+    // cycles inside s_waitcnt: a 96-byte record at a 96-byte stride is only 32-byte aligned, so it arrived as five
     // or six scalar loads, and the compiler waited (s_waitcnt lgkmcnt(0)) right behind every record's loads because
     // the test's early-out is a branch.  Now a record is ONE x16 and ONE x8 load, and the loads of the next record are
     // issued before the current one is tested (two register sets, alternating: no copies).  Same operations on the
