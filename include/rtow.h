@@ -199,22 +199,22 @@ int rtow_scene_upload(rtow_ctx *ctx, const rtow_scene_t *scene);
 /* Who builds the BVH image at rtow_scene_upload (replaces the reference's BVHNode constructor,
  * src/render.cpp:73-110, which runs on the host inside render()):
  *   HOST_SAH    binned surface-area-heuristic build on the host (best tree)
- *   DEVICE_LBVH Morton codes + radix sort + (round 5) parallel locally-ordered clustering over the sorted
- *               primitives + refit, all on the GPU (csrc/rtow_build.hip; RTOW_PLOC_RADIUS=0: Karras' radix
- *               tree of rounds 1-4) — for scenes rebuilt every frame and for big meshes at low sample
- *               counts; the uniform grid of the GRID kernel is then built on the GPU too
- *               (csrc/rtow_build_grid.hip, byte-identical to the host-built image), and for a triangle
- *               mesh the 4-wide image of the BVH4 kernel (greedy collapse of the binary tree level by
- *               level, breadth-first nodes, planes rounded outwards, records in leaf order): nothing of
- *               the build runs on the host.  96,800 triangles: 3.3 ms against 15 (host, 16 threads); the
- *               tree walks 7 % slower than the host's (rounds 1-4: 12 %).
- *   AUTO        (default of a new context) the device builder where it is expected to deliver the frame
- *               sooner, the host builder otherwise.  Decided per call by rtow_render / rtow_render_rgb8 /
- *               rtow_multi_upload-less paths that know their config: a scene of triangles only with at
- *               least 16,384 of them and fewer than 4,000 samples per triangle in the frame
- *               (image_width x image_height x effective spp: about 190 spp at 1920x1080 for 96,800
- *               triangles; the reference's default of 20 spp, src/render.h:15, is far below it).
- *               rtow_scene_upload, which knows no config, takes the host builder under AUTO.
+ *   DEVICE_LBVH on the GPU (csrc/rtow_build.hip): bounds, Morton keys and a radix sort, then (round 5) a binned
+ *               surface-area-heuristic build, top-down and level by level — the host builder's algorithm (16 bins
+ *               per axis, the split that minimises area x count over the three axes, a stable partition by one
+ *               scan per level) with every node of a level handled at once; refit; for a triangle mesh the
+ *               4-wide image of the BVH4 kernel (greedy collapse level by level, breadth-first nodes, planes
+ *               rounded outwards, records in leaf order); the uniform grid of the GRID kernel is built on the
+ *               GPU too (csrc/rtow_build_grid.hip, byte-identical to the host-built image).  Nothing of the
+ *               build runs on the host.  The tree is as good as the host's (suzanne: 9.0 node tests per segment
+ *               with either; 96,800 triangles: 20.5) and is built in 5 ms for 96,800 triangles against the
+ *               host's 12-16 on 16 threads.  RTOW_DEVICE_TREE=ploc|radix selects the earlier device trees
+ *               (parallel locally-ordered clustering, 7 % slower to walk; Karras' radix tree, 12 %).
+ *   AUTO        (default of a new context) per call of rtow_render / rtow_render_rgb8, which know their config:
+ *               the device builder for a scene of triangles only with 16,384 of them or more, the host builder
+ *               otherwise (a small mesh: the device's two dozen launches cost more than the host's 0.4 ms;
+ *               sphere scenes: the grid).  rtow_scene_upload, which knows no config, takes the host builder
+ *               under AUTO.
  * Images are bit-identical with either builder (the closest hit is tree-independent).
  * Takes effect at the next upload; the environment variable RTOW_BUILDER=host|device|auto sets the
  * default of new contexts.  rtow_build_info_t::builder says which one built the resident image. */

@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <utility>
 
 #include "rtow_device.h"
@@ -62,7 +63,24 @@ struct Scratch {
   uint32_t *pl_state = nullptr;  // [0] clusters in the array, [1] nodes created so far
   void *pl_scan_tmp = nullptr;
   size_t pl_scan_tmp_bytes = 0;
+  // binned SAH, top-down on the device (round 5, pass 3c): the primitives in two copies (the order is partitioned level by
+  // level), the node each position belongs to, per-node ranks in the level's work list, the work lists, per-rank
+  // centroid bounds / bins / split decisions, the partition's flags and their scan
+  uint32_t *sh_item[2] = {nullptr, nullptr};
+  int32_t *sh_node[2] = {nullptr, nullptr};
+  int32_t *sh_rank = nullptr, *sh_list[2] = {nullptr, nullptr};
+  uint32_t *sh_cnt = nullptr;       // [kSahMaxLevels + 2] nodes per level
+  uint32_t *sh_cb = nullptr;        // [ranks][6] centroid bounds (ordered u32)
+  uint32_t *sh_bin = nullptr;       // [ranks][48][7]: count, box min[3], box max[3] (ordered u32) per axis and bin
+  int32_t *sh_split = nullptr;      // [ranks][4]: axis, last bin of the left side, primitives on the left, mode
+  uint32_t *sh_flag = nullptr, *sh_scan = nullptr;
+  void *sh_scan_tmp = nullptr;
+  size_t sh_scan_tmp_bytes = 0;
+  size_t sh_ranks = 0;
 };
+constexpr int kSahMaxLevels = 160;   // hard bound on the depth of the split; from kSahMedianFrom on every split halves its range
+constexpr int kSahMedianFrom = 64;
+constexpr int kSahBins = 16;
 
 __device__ __forceinline__ uint32_t ordered(float f) {
   const uint32_t b = __float_as_uint(f);
@@ -365,6 +383,280 @@ __global__ void k_ploc_relabel(int n, const int32_t *pos, const int32_t *parent_
     if (l < 0) child_l[id] = pos[l & 0x7fffffff] | kLeafBit;
     if (r < 0) child_r[id] = pos[r & 0x7fffffff] | kLeafBit;
   }
+}
+
+// ---- pass 3c (round 5): the same arrays by a binned surface-area-heuristic build, top-down, on the device -------------
+// What the host builder does (rtow_bvh.h: 16 bins per axis over the node's centroid bounds, the split that minimises
+// area(L) n(L) + area(R) n(R) over the three axes, a partition of the node's primitives), level by level for all nodes at
+// once.  The prototype (scripts/experiments/ploc_proto.cpp) says where the device trees of this round fell short: PLOC
+// followed by an exact SAH over its last 2,048 / 8,192 / 32,768 clusters closes 27 / 44 / 82 % of its gap to the host
+// tree — the loss is in the top-down partition, not in the leaves; local restructuring (tree rotations) recovers nothing.
+// A node owns a RANGE [lo, hi] of the primitive order; a level partitions every active range in place (stable: one
+// exclusive scan over "goes right" flags), so ranges nest and are final from the moment they exist — Karras' numbering
+// applies (root 0; a left child is numbered by the last position of its range, a right child by the first), `first` /
+// `last` are the range, the leaves of a subtree are contiguous in the final order and no renumbering pass is needed.
+// One level = centroid bounds per node (atomics on order-preserving integers, one per wave when the wave lies inside
+// one node), bins per node (21 atomics per primitive), one thread per node choosing the split and creating the children,
+// the side of every primitive, ONE rocprim scan, the scatter.  Deterministic: the tree depends on no atomic's order
+// (sums of integers, minima and maxima), ties go to the lower axis and bin.  A node whose centroids coincide, and
+// every node from level kSahMedianFrom on, is split in the middle of its range.
+__device__ __forceinline__ float sah_centroid(const float *b, int k) { return 0.5f * (b[k] + b[3 + k]); }
+__device__ __forceinline__ int sah_bin_of(float c, float cmin, float cmax) {
+  const float scale = (float)kSahBins / (cmax - cmin);  // (cmax > cmin where this is called)
+  const int b = (int)((c - cmin) * scale);
+  return b < 0 ? 0 : (b > kSahBins - 1 ? kSahBins - 1 : b);
+}
+__global__ void k_sah_init(int n, const uint32_t *vals, uint32_t *item, int32_t *node, int32_t *first, int32_t *last,
+                           int32_t *parent_int, int32_t *rank, int32_t *list, uint32_t *cnt, uint32_t *cb, uint32_t *bin,
+                           size_t ranks) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) {
+    first[0] = 0;
+    last[0] = n - 1;
+    parent_int[0] = -1;
+    rank[0] = 0;
+    list[0] = 0;
+    cnt[0] = 1u;
+  }
+  if (j < (size_t)n) {
+    item[j] = vals[j];
+    node[j] = 0;
+  }
+  if (j < ranks * 6) cb[j] = (j % 6) < 3 ? 0xffffffffu : 0u;
+  for (size_t k = j; k < ranks * 48 * 7; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t f = k % 7;
+    bin[k] = f == 0 ? 0u : (f < 4 ? 0xffffffffu : 0u);
+  }
+}
+__global__ void k_sah_cb(int n, const uint32_t *item, const int32_t *node, const int32_t *rank, const float *pbox, uint32_t *cb) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nd = j < n ? node[j] : -1;
+  float c[3] = {0.f, 0.f, 0.f};
+  if (nd >= 0) {
+    const float *b = pbox + (size_t)item[j] * 6;
+    for (int k = 0; k < 3; ++k) c[k] = sah_centroid(b, k);
+  }
+  // a wave that lies inside one node (every wave of the top levels) reduces first: six atomics per wave
+  const int nd0 = __shfl(nd, 0);
+  const bool uniform = __all(nd == nd0);
+  if (uniform) {
+    if (nd0 < 0) return;
+    float mn[3] = {c[0], c[1], c[2]}, mx[3] = {c[0], c[1], c[2]};
+    for (int off = 32; off >= 1; off >>= 1)
+      for (int k = 0; k < 3; ++k) {
+        mn[k] = fminf(mn[k], __shfl_xor(mn[k], off));
+        mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
+      }
+    if ((threadIdx.x & 63u) == 0u) {
+      uint32_t *d = cb + (size_t)rank[nd0] * 6;
+      for (int k = 0; k < 3; ++k) {
+        atomicMin(&d[k], ordered(mn[k]));
+        atomicMax(&d[3 + k], ordered(mx[k]));
+      }
+    }
+  } else if (nd >= 0) {
+    uint32_t *d = cb + (size_t)rank[nd] * 6;
+    for (int k = 0; k < 3; ++k) {
+      atomicMin(&d[k], ordered(c[k]));
+      atomicMax(&d[3 + k], ordered(c[k]));
+    }
+  }
+}
+// Bins.  A WAVE whose 64 positions all lie inside one node (nodes are ranges, so: first and last position in the same
+// node — every wave of the first ten levels or so, where the primitives of a node would otherwise hammer the same 336
+// words) accumulates in its own slice of LDS and adds its non-empty bins to the node's: the 96,800-triangle mesh's first
+// levels took 2 ms each with one global atomic per primitive, axis and field.  Other waves (deep levels: many small
+// nodes, no contention) use one global atomic each.
+constexpr int kSahBinBlock = 1024;
+__global__ void __launch_bounds__(kSahBinBlock)
+    k_sah_bin(int n, const uint32_t *item, const int32_t *node, const int32_t *rank, const float *pbox, const uint32_t *cb,
+              uint32_t *bin) {
+  __shared__ uint32_t sh_all[(kSahBinBlock / 64) * 48 * 7];
+  const int lane = (int)(threadIdx.x & 63u);
+  uint32_t *sh = sh_all + (threadIdx.x >> 6) * (48 * 7);
+  const int j = blockIdx.x * kSahBinBlock + (int)threadIdx.x;
+  const int w0 = j - lane, w1 = min(w0 + 63, n - 1);
+  const int nd_first = w0 < n ? node[w0] : -1, nd_last = w0 < n ? node[w1] : -1;
+  // (wave-uniform.  Two finished positions at the ends of a wave say nothing about its middle.)
+  const bool one_node = nd_first >= 0 && nd_first == nd_last;
+  if (one_node)
+    for (int k = lane; k < 48 * 7; k += 64) sh[k] = (k % 7) == 0 ? 0u : ((k % 7) < 4 ? 0xffffffffu : 0u);
+  __syncthreads();
+  const int nd = j < n ? node[j] : -1;
+  if (nd >= 0) {
+    const size_t r = (size_t)rank[nd];
+    const float *b = pbox + (size_t)item[j] * 6;
+    for (int a = 0; a < 3; ++a) {
+      const float cmin = unordered(cb[r * 6 + a]), cmax = unordered(cb[r * 6 + 3 + a]);
+      if (!(cmax > cmin)) continue;  // (no split along an axis on which the centroids coincide)
+      const int slot = (a * kSahBins + sah_bin_of(sah_centroid(b, a), cmin, cmax)) * 7;
+      uint32_t *d = one_node ? sh + slot : bin + r * 48 * 7 + slot;
+      atomicAdd(&d[0], 1u);
+      for (int k = 0; k < 3; ++k) {
+        atomicMin(&d[1 + k], ordered(b[k]));
+        atomicMax(&d[4 + k], ordered(b[3 + k]));
+      }
+    }
+  }
+  __syncthreads();
+  if (one_node) {
+    uint32_t *g = bin + (size_t)rank[nd_first] * 48 * 7;
+    for (int k = lane; k < 48 * 7; k += 64) {
+      const int f = k % 7;
+      const uint32_t v = sh[k];
+      if (f == 0) {
+        if (v != 0u) atomicAdd(&g[k], v);
+      } else if (sh[k - f] != 0u) {  // (a bin that got primitives)
+        if (f < 4) atomicMin(&g[k], v); else atomicMax(&g[k], v);
+      }
+    }
+  }
+}
+// one thread per node of the level: the split, the children, the next level's work list; resets the node's accumulators
+__global__ void k_sah_split(int level, int force_median, const int32_t *list, int32_t *list_next, uint32_t *cnt, int32_t *rank,
+                            uint32_t *cb, uint32_t *bin, int32_t *split, int32_t *child_l, int32_t *child_r, int32_t *first,
+                            int32_t *last, int32_t *parent_int, int32_t *parent_leaf) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cnt[level]) return;
+  const int nd = list[t];
+  const int lo = first[nd], hi = last[nd], size = hi - lo + 1;
+  int best_axis = -1, best_bin = 0, best_nl = size / 2;
+  float best_cost = INFINITY;
+  for (int a = 0; a < 3 && !force_median; ++a) {
+    const float cmin = unordered(cb[(size_t)t * 6 + a]), cmax = unordered(cb[(size_t)t * 6 + 3 + a]);
+    if (!(cmax > cmin)) continue;
+    const uint32_t *B = bin + ((size_t)t * 3 + a) * kSahBins * 7;
+    // suffix areas and counts: right side = bins b + 1 .. 15
+    float r_area[kSahBins];
+    uint32_t r_cnt[kSahBins];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t c = 0;
+    for (int b = kSahBins - 1; b >= 1; --b) {
+      if (B[b * 7] != 0u) {
+        c += B[b * 7];
+        for (int k = 0; k < 3; ++k) {
+          mn[k] = fminf(mn[k], unordered(B[b * 7 + 1 + k]));
+          mx[k] = fmaxf(mx[k], unordered(B[b * 7 + 4 + k]));
+        }
+      }
+      const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+      r_area[b] = c ? dx * dy + dy * dz + dz * dx : 0.f;
+      r_cnt[b] = c;
+    }
+    for (int k = 0; k < 3; ++k) mn[k] = INFINITY, mx[k] = -INFINITY;
+    c = 0;
+    for (int b = 0; b < kSahBins - 1; ++b) {  // split after bin b
+      if (B[b * 7] != 0u) {
+        c += B[b * 7];
+        for (int k = 0; k < 3; ++k) {
+          mn[k] = fminf(mn[k], unordered(B[b * 7 + 1 + k]));
+          mx[k] = fmaxf(mx[k], unordered(B[b * 7 + 4 + k]));
+        }
+      }
+      if (c == 0u || r_cnt[b + 1] == 0u) continue;
+      const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+      const float cost = (dx * dy + dy * dz + dz * dx) * (float)c + r_area[b + 1] * (float)r_cnt[b + 1];
+      if (cost < best_cost) {  // ties: the lower axis, the lower bin
+        best_cost = cost;
+        best_axis = a;
+        best_bin = b;
+        best_nl = (int)c;
+      }
+    }
+  }
+  if (!force_median) {
+    uint32_t *B0 = bin + (size_t)t * 48 * 7;
+    for (int k = 0; k < 48 * 7; ++k) {
+      const int f = k % 7;
+      B0[k] = f == 0 ? 0u : (f < 4 ? 0xffffffffu : 0u);
+    }
+  }
+  int32_t *sp = split + (size_t)t * 4;
+  sp[0] = best_axis;
+  sp[1] = best_bin;
+  sp[2] = best_nl;
+  sp[3] = best_axis < 0 ? 1 : 0;  // mode 1: by position (the first best_nl of the range go left)
+  // children: [lo, lo + nl - 1] and [lo + nl, hi]
+  const int nl = best_nl, g = lo + nl - 1;
+  const bool leaf_l = nl == 1, leaf_r = size - nl == 1;
+  child_l[nd] = leaf_l ? (g | kLeafBit) : g;            // a left child is numbered by the last position of its range
+  child_r[nd] = leaf_r ? ((g + 1) | kLeafBit) : g + 1;  // a right child by the first
+  uint32_t k = 0;
+  if (!leaf_l || !leaf_r) k = atomicAdd(&cnt[level + 1], (leaf_l ? 0u : 1u) + (leaf_r ? 0u : 1u));
+  if (leaf_l) {
+    parent_leaf[g] = nd;
+  } else {
+    parent_int[g] = nd;
+    first[g] = lo;
+    last[g] = g;
+    rank[g] = (int32_t)k;
+    list_next[k++] = g;
+  }
+  if (leaf_r) {
+    parent_leaf[g + 1] = nd;
+  } else {
+    parent_int[g + 1] = nd;
+    first[g + 1] = g + 1;
+    last[g + 1] = hi;
+    rank[g + 1] = (int32_t)k;
+    list_next[k] = g + 1;
+  }
+}
+// (the accumulators of the ranks used by this level back to their identities, after the side kernel has read them)
+__global__ void k_sah_reset(int level, const uint32_t *cnt, uint32_t *cb, uint32_t *bin) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t used = cnt[level];
+  if (i < used * 6) cb[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+  if (i < used * 48 * 7) {
+    const size_t f = i % 7;
+    bin[i] = f == 0 ? 0u : (f < 4 ? 0xffffffffu : 0u);
+  }
+}
+__global__ void k_sah_side(int n, const uint32_t *item, const int32_t *node, const int32_t *rank, const float *pbox,
+                           const uint32_t *cb, const int32_t *split, const int32_t *first, uint32_t *flag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int nd = node[j];
+  uint32_t right = 0u;
+  if (nd >= 0) {
+    const size_t r = (size_t)rank[nd];
+    const int32_t *sp = split + r * 4;
+    if (sp[3] != 0) {
+      right = (j - first[nd]) >= sp[2] ? 1u : 0u;
+    } else {
+      const int a = sp[0];
+      const float cmin = unordered(cb[r * 6 + a]), cmax = unordered(cb[r * 6 + 3 + a]);
+      right = sah_bin_of(sah_centroid(pbox + (size_t)item[j] * 6, a), cmin, cmax) > sp[1] ? 1u : 0u;
+    }
+  }
+  flag[j] = right;
+}
+__global__ void k_sah_scatter(int n, const uint32_t *item, const int32_t *node, const int32_t *rank, const int32_t *split,
+                              const int32_t *first, const int32_t *last, const uint32_t *flag, const uint32_t *scan,
+                              uint32_t *item_out, int32_t *node_out, uint32_t *cb) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int nd = node[j];
+  if (nd < 0) {  // a finished position keeps its primitive
+    item_out[j] = item[j];
+    node_out[j] = -1;
+    return;
+  }
+  const int lo = first[nd], hi = last[nd];
+  const int nl = split[(size_t)rank[nd] * 4 + 2], nr = hi - lo + 1 - nl;
+  if (j == lo) {  // (k_sah_side, the last reader of this node's centroid bounds, has run)
+    uint32_t *d = cb + (size_t)rank[nd] * 6;
+    for (int k = 0; k < 3; ++k) d[k] = 0xffffffffu, d[3 + k] = 0u;
+  }
+  const int rights_before = (int)(scan[j] - scan[lo]);
+  const bool right = flag[j] != 0u;
+  const int pos = right ? lo + nl + rights_before : lo + (j - lo) - rights_before;
+  item_out[pos] = item[j];
+  node_out[pos] = right ? (nr >= 2 ? lo + nl : -1) : (nl >= 2 ? lo + nl - 1 : -1);
+}
+__global__ void k_sah_finish(int n, const uint32_t *item, uint32_t *vals) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) vals[j] = item[j];
 }
 
 // ---- pass 4: bottom-up boxes, emitted-subtree sizes, near-child-first bit ------------------
@@ -674,7 +966,9 @@ void release(Scratch *s) {
                   s->ibox,     s->size,    s->flags,      s->glob,        s->sort_tmp,
                   s->b4_src,   s->b4_child, s->b4_cw,     s->b4_cnt,      s->b4_pos, s->scan_tmp, s->b4_seen,
                   s->pl_ref[0], s->pl_ref[1], s->pl_box[0], s->pl_box[1], s->pl_nn, s->pl_flag, s->pl_scan,
-                  s->pl_cnt,   s->pl_pos,  s->pl_parent_leaf, s->pl_state, s->pl_scan_tmp};
+                  s->pl_cnt,   s->pl_pos,  s->pl_parent_leaf, s->pl_state, s->pl_scan_tmp,
+                  s->sh_item[0], s->sh_item[1], s->sh_node[0], s->sh_node[1], s->sh_rank, s->sh_list[0], s->sh_list[1],
+                  s->sh_cnt,   s->sh_cb,   s->sh_bin, s->sh_split, s->sh_flag, s->sh_scan, s->sh_scan_tmp};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   delete s;
@@ -690,7 +984,8 @@ bool dev_alloc(T *&p, size_t count) {
 // Phase 1: builds the tree in scratch memory.  Returns 0 and the number of node records the
 // image will hold (without the END record).  `*handle` is the scratch: NULL on the first call,
 // reused (and grown when needed) by later builds, released with lbvh_release.
-// `ploc_radius`: > 0 = PLOC with that search radius (pass 3b), 0 = Karras' radix tree (pass 3).
+// `ploc_radius`: > 0 = PLOC with that search radius (pass 3b), 0 = Karras' radix tree (pass 3), < 0 = the binned SAH
+// build (pass 3c).
 int lbvh_build(const double *sph, const double *sph_r, const double *mov, const double *tri, int ns, int nm,
                int nt, double time0, double time1, const double cam_origin[3], int leaf_max, void *stream,
                void **handle, int *n_nodes, int ploc_radius) {
@@ -738,7 +1033,64 @@ int lbvh_build(const double *sph, const double *sph_r, const double *mov, const 
     good = rocprim::radix_sort_pairs(s->sort_tmp, tmp_bytes, s->keys_a, s->keys_b, s->vals_a, s->vals_b, (size_t)n, 0u, 63u, st) == hipSuccess;
   }
   int32_t root_size = 1;
-  if (good && n > 2 && ploc_radius > 0) {
+  if (good && n > 2 && ploc_radius < 0) {
+    const size_t cap = (size_t)s->capacity, ranks = cap / 2 + 2;
+    if (!s->sh_cnt) {
+      bool ok = dev_alloc(s->sh_item[0], cap) && dev_alloc(s->sh_item[1], cap) && dev_alloc(s->sh_node[0], cap) &&
+                dev_alloc(s->sh_node[1], cap) && dev_alloc(s->sh_rank, cap) && dev_alloc(s->sh_list[0], cap) &&
+                dev_alloc(s->sh_list[1], cap) && dev_alloc(s->sh_cnt, (size_t)kSahMaxLevels + 2) &&
+                dev_alloc(s->sh_cb, ranks * 6) && dev_alloc(s->sh_bin, ranks * 48 * 7) && dev_alloc(s->sh_split, ranks * 4) &&
+                dev_alloc(s->sh_flag, cap) && dev_alloc(s->sh_scan, cap);
+      if (ok)
+        ok = rocprim::exclusive_scan(nullptr, s->sh_scan_tmp_bytes, s->sh_flag, s->sh_scan, 0u, cap, rocprim::plus<uint32_t>(), st) == hipSuccess &&
+             hipMalloc(&s->sh_scan_tmp, s->sh_scan_tmp_bytes ? s->sh_scan_tmp_bytes : 16) == hipSuccess;
+      if (!ok) return 2;
+      s->sh_ranks = ranks;
+    }
+    good = hipMemsetAsync(s->sh_cnt, 0, ((size_t)kSahMaxLevels + 2) * sizeof(uint32_t), st) == hipSuccess;
+    {
+      const size_t init_threads = std::max<size_t>((size_t)n, s->sh_ranks * 48 * 7 / 8);
+      hipLaunchKernelGGL(k_sah_init, dim3((unsigned)((init_threads + B - 1) / B)), dim3(B), 0, st, n, s->vals_b, s->sh_item[0],
+                         s->sh_node[0], s->first, s->last, s->parent_int, s->sh_rank, s->sh_list[0], s->sh_cnt, s->sh_cb, s->sh_bin,
+                         s->sh_ranks);
+    }
+    bool done = false;
+    int level = 0;
+    for (; good && !done && level < kSahMaxLevels; ++level) {
+      const int in = level & 1, out = in ^ 1;
+      // a level holds at most min(2^level, n / 2) nodes of two or more primitives
+      const long long most = level < 30 ? std::min<long long>(1ll << level, n / 2 + 1) : (long long)(n / 2 + 1);
+      const int Gn = (int)((most + B - 1) / B);
+      const int force_median = level >= kSahMedianFrom ? 1 : 0;
+      if (!force_median) {
+        hipLaunchKernelGGL(k_sah_cb, dim3(G), dim3(B), 0, st, n, s->sh_item[in], s->sh_node[in], s->sh_rank, s->pbox, s->sh_cb);
+        hipLaunchKernelGGL(k_sah_bin, dim3((n + kSahBinBlock - 1) / kSahBinBlock), dim3(kSahBinBlock), 0, st, n, s->sh_item[in],
+                           s->sh_node[in], s->sh_rank, s->pbox, s->sh_cb, s->sh_bin);
+      }
+      hipLaunchKernelGGL(k_sah_split, dim3(Gn), dim3(B), 0, st, level, force_median, s->sh_list[in], s->sh_list[out], s->sh_cnt,
+                         s->sh_rank, s->sh_cb, s->sh_bin, s->sh_split, s->child_l, s->child_r, s->first, s->last, s->parent_int,
+                         s->parent_leaf);
+      hipLaunchKernelGGL(k_sah_side, dim3(G), dim3(B), 0, st, n, s->sh_item[in], s->sh_node[in], s->sh_rank, s->pbox, s->sh_cb,
+                         s->sh_split, s->first, s->sh_flag);
+      size_t tb = s->sh_scan_tmp_bytes;
+      good = rocprim::exclusive_scan(s->sh_scan_tmp, tb, s->sh_flag, s->sh_scan, 0u, (size_t)n, rocprim::plus<uint32_t>(), st) == hipSuccess;
+      if (!good) break;
+      hipLaunchKernelGGL(k_sah_scatter, dim3(G), dim3(B), 0, st, n, s->sh_item[in], s->sh_node[in], s->sh_rank, s->sh_split,
+                         s->first, s->last, s->sh_flag, s->sh_scan, s->sh_item[out], s->sh_node[out], s->sh_cb);
+      // (the node's accumulators go back to their identities inside the level: the bins by the thread that read them in
+      // k_sah_split, the centroid bounds by the node's first position in k_sah_scatter, behind their last reader)
+      if ((level & 7) == 7 || level + 1 == kSahMaxLevels) {
+        uint32_t next_n = 1;
+        good = hipMemcpyAsync(&next_n, s->sh_cnt + level + 1, 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+               hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+        done = next_n == 0u;
+      }
+    }
+    if (good && !done) return 3;  // (cannot happen: from level kSahMedianFrom on every split halves its range)
+    if (good) {
+      hipLaunchKernelGGL(k_sah_finish, dim3(G), dim3(B), 0, st, n, s->sh_item[level & 1], s->vals_b);
+    }
+  } else if (good && n > 2 && ploc_radius > 0) {
     const size_t cap = (size_t)s->capacity;
     if (!s->pl_state) {
       bool ok = dev_alloc(s->pl_ref[0], cap) && dev_alloc(s->pl_ref[1], cap) && dev_alloc(s->pl_box[0], cap * 6) &&

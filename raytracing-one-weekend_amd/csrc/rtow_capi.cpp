@@ -279,6 +279,8 @@ struct Knobs {
                                   //   4 / 8 / 16 / 32 samples: 4.60 / 4.64 / 4.69 / 4.68 Gsamples/s on C4, 2.29 / 2.30 / 2.32 / 2.32 on C5)
   int ploc_radius = -1;           // RTOW_PLOC_RADIUS: device builder: search radius of the PLOC pass (csrc/rtow_build.hip, round 5);
                                   //   0 = Karras' radix tree (rounds 1-4); -1 = default: 16 up to 16,384 primitives, 8 above
+  int device_tree = 2;            // RTOW_DEVICE_TREE=radix|ploc|sah: how the device builder makes its binary tree (0 / 1 / 2);
+                                  //   sah = binned surface-area heuristic, top-down, level by level (pass 3c): the default
   bool no_spec = false;           // RTOW_NO_SPEC: always the generic GRID kernel (A/B against the scene-class specialisations)
   int tail_bound = 0;             // RTOW_TAIL_BOUND (tests only): trips of the end-of-launch protocol before a wave gives up
                                   //   its samples (0 = the structural bound); a small value forces the RTOW_EHIP path
@@ -327,6 +329,9 @@ struct Knobs {
     tail_bound = std::max(geti("RTOW_TAIL_BOUND", 0), 0);
     no_spec = std::getenv("RTOW_NO_SPEC") != nullptr;
     if (const char *e = std::getenv("RTOW_PLOC_RADIUS")) ploc_radius = std::min(std::max(std::atoi(e), 0), 64);
+    if (const char *e = std::getenv("RTOW_DEVICE_TREE"))
+      device_tree = std::strcmp(e, "radix") == 0 ? 0 : (std::strcmp(e, "ploc") == 0 ? 1 : 2);
+    if (ploc_radius >= 0 && !std::getenv("RTOW_DEVICE_TREE")) device_tree = ploc_radius == 0 ? 0 : 1;  // (the radius alone selects PLOC / radix)
   }
 };
 
@@ -653,7 +658,10 @@ static int scene_upload(rtow_ctx *c, const rtow_scene_t *s, unsigned need) {
     int brc = rtow::lbvh_build((const double *)c->sph.p, (const double *)c->sph_r.p, (const double *)c->mov.p,
                                (const double *)c->tri.p, ns, nm, nt, s->camera.t0, s->camera.t1, s->camera.origin,
                                leaf_max, nullptr, &c->lbvh_scratch, &n_nodes,
-                               c->knobs.ploc_radius >= 0 ? c->knobs.ploc_radius : (ns + nm + nt <= 16384 ? 16 : 8));
+                               c->knobs.device_tree == 2   ? -1
+                               : c->knobs.device_tree == 0 ? 0
+                               : c->knobs.ploc_radius > 0  ? c->knobs.ploc_radius
+                                                           : (ns + nm + nt <= 16384 ? 16 : 8));
     if (brc) return fail(RTOW_EHIP, "device BVH build failed (stage %d): %s", brc, hipGetErrorString(hipGetLastError()));
     if (want2) {
     rtow::layout_scene_image(n_nodes, (size_t)(ns + nm + nt), sph, mov, tri, pmat, mats_bytes, img, true);
@@ -1626,14 +1634,11 @@ static int upload_for(rtow_ctx *c, const rtow_scene_t *scene, const rtow_config_
   else
     need = kNeedBvh;
   if (c->builder_req == RTOW_BUILDER_AUTO) {
-    // AUTO (include/rtow.h): the device builder where the frame is short against the host build it saves — a big
-    // triangle mesh at a low sample count.  Measured on the 96,800-triangle mesh: host 15 ms,
-    // device 3.3 ms, the device-built tree walks 7 % slower at 2.46 Gsamples/s => break-even near 4,000 samples per
-    // triangle.
-    const long long spp_eff = (long long)(cfg->samples_per_pixel / cfg->nstreams) * cfg->nstreams;
-    const long long samples = (long long)cfg->image_width * rtow_local_rows(cfg) * spp_eff;
-    const bool device = mesh && need == kNeedBvh4 && scene->n_triangles >= 16384 &&
-                        samples < 4000ll * (long long)scene->n_triangles;
+    // AUTO (include/rtow.h): the device builder where it delivers the frame sooner.  Its tree is the host's (binned SAH,
+    // csrc/rtow_build.hip pass 3c: the same node and triangle tests per segment), so what decides is the build: a fixed
+    // ~1.7 ms of launches plus ~0.055 us per triangle on the device, ~0.15 us per triangle on the host's 16 threads
+    // (96,800 triangles: 7 against 12-16 ms) — the device from about 16,000 triangles on, at any sample count.
+    const bool device = mesh && need == kNeedBvh4 && scene->n_triangles >= 16384;
     c->builder = device ? RTOW_BUILDER_DEVICE_LBVH : RTOW_BUILDER_HOST_SAH;
   }
   rc = scene_upload(c, scene, need);

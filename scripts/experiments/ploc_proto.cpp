@@ -114,6 +114,42 @@ static Score score(const Tree &t, const std::vector<B> &leaf, int n) {
   return s;
 }
 
+
+// Tree rotations (Kensler 2008): for an inner node with children L, R, swap a child with a grandchild on the other
+// side when that lowers the surface area of the child that is rebuilt.  Passes over all nodes until nothing improves
+// (or `max_pass`).  Boxes and counts are kept up to date locally; ancestors' boxes do not change (same leaf sets).
+static int rotate_pass(Tree &t, const std::vector<B> &leaf, const std::vector<int> &order) {
+  auto box = [&](int ref) -> B { return ref < 0 ? leaf[~ref] : t.box[ref]; };
+  auto cnt = [&](int ref) { return ref < 0 ? 1 : t.cnt[ref]; };
+  int done = 0;
+  for (int id : order) {
+    int &L = t.l[id], &R = t.r[id];
+    // candidates: swap R with a grandchild under L (L is rebuilt), or L with a grandchild under R
+    float best = 0.f;
+    int which = -1;
+    for (int side = 0; side < 2; ++side) {
+      const int child = side == 0 ? L : R, other = side == 0 ? R : L;
+      if (child < 0) continue;
+      const float a0 = t.box[child].area();
+      const int g0 = t.l[child], g1 = t.r[child];
+      const float a_swap0 = uni(box(other), box(g1)).area();  // other replaces g0
+      const float a_swap1 = uni(box(g0), box(other)).area();  // other replaces g1
+      if (a0 - a_swap0 > best) best = a0 - a_swap0, which = side * 2;
+      if (a0 - a_swap1 > best) best = a0 - a_swap1, which = side * 2 + 1;
+    }
+    if (which < 0) continue;
+    const int side = which >> 1, gi = which & 1;
+    int &child = side == 0 ? L : R;
+    int &other = side == 0 ? R : L;
+    int &g = gi == 0 ? t.l[child] : t.r[child];
+    std::swap(other, g);
+    t.box[child] = uni(box(t.l[child]), box(t.r[child]));
+    t.cnt[child] = cnt(t.l[child]) + cnt(t.r[child]);
+    ++done;
+  }
+  return done;
+}
+
 static uint64_t spread21(uint64_t v) {
   v &= 0x1fffffull;
   v = (v | (v << 32)) & 0x1f00000000ffffull;
@@ -249,7 +285,7 @@ int main(int argc, char **argv) {
     std::printf("radix   : 4-wide nodes %6d depth %2d  metric nodes %.3f tris %.3f\n", s.n4, s.depth, s.nodes, s.tris);
   }
   // ---- PLOC, optionally stopped at `stop` clusters and finished by an exact sweep-SAH over the clusters
-  for (int stop : {1, 512, 2048, 8192})
+  for (int stop : {1, 2048, 8192, 32768, 1000000})
   for (int R : {8, 16}) {
     Tree t;
     t.l.assign(n, 0), t.r.assign(n, 0), t.cnt.assign(n, 0), t.box.resize(n);
@@ -339,6 +375,38 @@ int main(int argc, char **argv) {
       t.root = ref[0];
     }
     finish(t);
+    if (stop == 1) {
+      // top-down order of the inner nodes
+      std::vector<int> order;
+      std::vector<int> st2{t.root};
+      while (!st2.empty()) {
+        const int id = st2.back();
+        st2.pop_back();
+        order.push_back(id);
+        if (t.l[id] >= 0) st2.push_back(t.l[id]);
+        if (t.r[id] >= 0) st2.push_back(t.r[id]);
+      }
+      const Score s0 = score(t, leaf, n);
+      int passes = 0, total = 0;
+      for (; passes < 16; ++passes) {
+        const int k = rotate_pass(t, leaf, order);
+        total += k;
+        if (k == 0) break;
+        order.clear();
+        st2.assign(1, t.root);
+        while (!st2.empty()) {
+          const int id = st2.back();
+          st2.pop_back();
+          order.push_back(id);
+          if (t.l[id] >= 0) st2.push_back(t.l[id]);
+          if (t.r[id] >= 0) st2.push_back(t.r[id]);
+        }
+      }
+      finish(t);
+      const Score s1 = score(t, leaf, n);
+      std::printf("ploc %2d + rotations (%d passes, %d rotations): nodes %.3f -> %.3f tris %.3f -> %.3f, 4-wide nodes %d\n", R, passes, total,
+                  s0.nodes, s1.nodes, s0.tris, s1.tris, s1.n4);
+    }
     const Score s = score(t, leaf, n);
     std::printf("ploc %2d stop %5d: 4-wide nodes %6d depth %2d  metric nodes %.3f tris %.3f  (%d iterations)\n", R, stop, s.n4, s.depth,
                 s.nodes, s.tris, iters);

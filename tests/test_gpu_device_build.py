@@ -276,9 +276,10 @@ def test_device_built_bvh4_image_strict_is_bit_identical_to_oracle(dctx, tmp_pat
         c.close()
 
 
-def test_ploc_tree_and_radix_tree_give_the_same_image_and_ploc_has_fewer_node_tests(tmp_path, monkeypatch):
-    """Round 5: the device builder's binary tree comes from parallel locally-ordered clustering over the Morton order
-    (csrc/rtow_build.hip pass 3b) instead of Karras' radix tree (RTOW_PLOC_RADIUS=0).  Same image bit for bit (the
+def test_device_trees_radix_ploc_sah_give_the_same_image_and_the_sah_tree_is_the_best(tmp_path, monkeypatch):
+    """Round 5: the device builder's binary tree comes from a binned SAH build (csrc/rtow_build.hip pass 3c, the
+    default), from parallel locally-ordered clustering over the Morton order (pass 3b, RTOW_PLOC_RADIUS=8|16) or from
+    Karras' radix tree (pass 3, RTOW_PLOC_RADIUS=0: rounds 1-4).  Same image bit for bit (the
     closest hit is tree-independent), fewer node tests per segment, and the device-side validation has counted every
     triangle record in exactly one leaf (rtow_scene_upload fails otherwise)."""
     sys.path.insert(0, str(REPO / "scripts"))
@@ -289,8 +290,12 @@ def test_ploc_tree_and_radix_tree_give_the_same_image_and_ploc_has_fewer_node_te
     for obj, nt in ((GOLDEN / "suzanne.obj", 968), (tmp_path / "m3.obj", 8712)):
         scene = rtow.HostScene.obj(obj, 16 / 9)
         out = {}
-        for radius in ("0", "8", "16"):
-            monkeypatch.setenv("RTOW_PLOC_RADIUS", radius)
+        for radius in ("0", "8", "16", "sah"):
+            if radius == "sah":
+                monkeypatch.delenv("RTOW_PLOC_RADIUS", raising=False)
+                monkeypatch.setenv("RTOW_DEVICE_TREE", "sah")
+            else:
+                monkeypatch.setenv("RTOW_PLOC_RADIUS", radius)
             c = rtow.Context(0)  # (the knob is read at context creation)
             try:
                 c.set_builder(rtow.BUILDER_DEVICE_LBVH)
@@ -301,7 +306,8 @@ def test_ploc_tree_and_radix_tree_give_the_same_image_and_ploc_has_fewer_node_te
                     out[(radius, kernel)] = (img, st.segments, st.node_tests / st.segments)
             finally:
                 c.close()
-        monkeypatch.delenv("RTOW_PLOC_RADIUS")
+        monkeypatch.delenv("RTOW_PLOC_RADIUS", raising=False)
+        monkeypatch.delenv("RTOW_DEVICE_TREE", raising=False)
         ref = out[("0", rtow.KERNEL_BVH4)]
         for key, (img, seg, _) in out.items():
             assert seg == ref[1] and np.array_equal(img, ref[0]), (nt, key)
@@ -312,13 +318,16 @@ def test_ploc_tree_and_radix_tree_give_the_same_image_and_ploc_has_fewer_node_te
             assert out[("16", rtow.KERNEL_BVH4)][2] < 0.95 * radix, (radix, out[("16", rtow.KERNEL_BVH4)][2])
         for radius in ("8", "16"):
             assert out[(radius, rtow.KERNEL_BVH4)][2] < 1.03 * radix, (nt, radius)
+        # the binned SAH build on the device (the default): suzanne 9.0, the host tree's number
+        assert out[("sah", rtow.KERNEL_BVH4)][2] < (0.85 if nt == 968 else 1.0) * radix, (nt, radix, out[("sah", rtow.KERNEL_BVH4)][2])
 
 
-def test_auto_builder_takes_the_device_for_a_big_mesh_at_a_low_sample_count(tmp_path):
-    """RTOW_BUILDER_AUTO, the default of a new context (include/rtow.h): rtow_render knows its config and builds a mesh
-    of 16,384 triangles or more on the device when the frame has fewer than 4,000 samples per triangle (the 15 ms
-    host build would be longer than what its better tree saves); small meshes, sphere scenes and long frames take the
-    host builder; rtow_scene_upload, which knows no config, takes the host builder.  Same image either way."""
+def test_auto_builder_takes_the_device_for_big_meshes(tmp_path):
+    """RTOW_BUILDER_AUTO, the default of a new context (include/rtow.h): rtow_render* builds a mesh of 16,384 triangles
+    or more on the device — the binned SAH build of csrc/rtow_build.hip makes the host builder's tree (same node and
+    triangle tests per segment) in a third of its time — and everything else on the host (a small mesh: the device's
+    two dozen launches cost more than the host's 0.4 ms; sphere scenes: the grid); rtow_scene_upload, which knows no
+    config, takes the host builder.  Same image either way."""
     subprocess.run([sys.executable, str(REPO / "scripts" / "make_mesh.py"), str(tmp_path / "m5.obj"), "5"], check=True,
                    capture_output=True)
     mesh = rtow.HostScene.obj(tmp_path / "m5.obj", 16 / 9)  # 24,200 triangles
@@ -327,19 +336,22 @@ def test_auto_builder_takes_the_device_for_a_big_mesh_at_a_low_sample_count(tmp_
     c = rtow.Context(0)
     try:
         low = rtow.make_config(160, 90, 4, 2, 20, seed=3, precision=rtow.F64_STRICT)
-        img, st = c.render(mesh, low)  # 57,600 samples < 4,000 x 24,200
+        img, st = c.render(mesh, low)
         assert c.build_info().builder == rtow.BUILDER_DEVICE_LBVH and st.kernel_used == rtow.KERNEL_BVH4
+        dev_tests = (st.node_tests / st.segments, st.prim_tests / st.segments)
         c.set_builder(rtow.BUILDER_HOST_SAH)
-        himg, _ = c.render(mesh, low)
+        himg, hst = c.render(mesh, low)
         assert c.build_info().builder == rtow.BUILDER_HOST_SAH and np.array_equal(img, himg)
+        # the device's tree is as good as the host's: node and triangle tests per segment within 3 %
+        host_tests = (hst.node_tests / hst.segments, hst.prim_tests / hst.segments)
+        assert abs(dev_tests[0] / host_tests[0] - 1) < 0.03 and abs(dev_tests[1] / host_tests[1] - 1) < 0.03, (dev_tests, host_tests)
         c.set_builder(rtow.BUILDER_AUTO)
+        c.render_rgb8(mesh, rtow.make_config(640, 360, 64, 4, 20, seed=3, precision=rtow.F64_FAST))  # a longer frame: still the device
+        assert c.build_info().builder == rtow.BUILDER_DEVICE_LBVH
         c.render(small, low)
         assert c.build_info().builder == rtow.BUILDER_HOST_SAH  # 968 triangles
         c.render(cover, rtow.make_config(96, 64, 4, 2, 10, seed=3, precision=rtow.F64_FAST))
         assert c.build_info().builder == rtow.BUILDER_HOST_SAH  # spheres: the grid, host-built
-        long = rtow.make_config(1920, 1080, 48, 3, 20, seed=3, precision=rtow.F64_FAST)  # 99.5 M samples >= 96.8 M
-        c.render_rgb8(mesh, long)
-        assert c.build_info().builder == rtow.BUILDER_HOST_SAH
         c.upload(mesh)
         assert c.build_info().builder == rtow.BUILDER_HOST_SAH  # no config: host
     finally:
