@@ -79,7 +79,7 @@ static void usage(const char *argv0) {
                "                              reference's own median-split tree and f64 box test, strict arithmetic)\n"
                "  --primitives oo|variant|world  scene model the scripts build (the reference picks at compile time;\n"
                "                              world = src/vmodel.h, spheres only)\n"
-               "  --builder host|device|auto  BVH build: host SAH, on the GPU (PLOC), or (default) whichever delivers the frame sooner\n"
+               "  --builder host|device|auto  BVH build: binned SAH on the host, the same on the GPU, or (default) whichever delivers the frame sooner\n"
                "  --p6                        binary P6 output, write_color on the device\n"
                "  --general-obj               with -l: load every shape, not only the first\n"
                "  --gpus INT                  tile-split over INT devices (--device is the first), strips gathered\n"

@@ -322,7 +322,7 @@ static void render_flat(FlatScene *flat, const Config &cfg) {
   // structures this render's kernel reads are built)
   if (bi.bvh_image_bytes > 0)
     std::cerr << "BVH image: " << bi.bvh_nodes << " nodes, " << bi.bvh_image_bytes << " bytes, built on the "
-              << (bi.builder == RTOW_BUILDER_DEVICE_LBVH ? "device (PLOC)" : "host (SAH)") << " in " << bi.bvh_build_ms
+              << (bi.builder == RTOW_BUILDER_DEVICE_LBVH ? "device" : "host (SAH)") << " in " << bi.bvh_build_ms
               << " ms" << (bi.bvh4_nodes > 0 ? "; 4-wide image: " + std::to_string(bi.bvh4_nodes) + " nodes of " + std::to_string(bi.bvh4_node_bytes) + " bytes"
                                    : std::string()) << "\n";
   if (bi.grid_image_bytes > 0)
@@ -330,6 +330,10 @@ static void render_flat(FlatScene *flat, const Config &cfg) {
   std::cerr << "Traced " << st.samples << " samples, " << st.segments << " ray segments; kernel "
             << st.kernel_ms << " ms ("
             << (st.kernel_ms > 0 ? st.samples / st.kernel_ms / 1e3 : 0.0) << " Msamples/s)\n";
+  // The reference counts scanlines down on stderr as each of its threads works through the image
+  // (src/render.cpp:154).  Here every row was finished by the one call above, so the countdown has a single
+  // state left to show — its last one; `\nDone in` follows it exactly as in the reference (:188-189).
+  std::cerr << "\rScanlines remaining: " << 0 << ' ' << std::flush;
   std::cerr << "\nDone in " << khr::duration_cast<khr::milliseconds>(took).count() << "ms\n";
 }
 

@@ -29,7 +29,7 @@ struct DeviceOptions {
   uint64_t seed = 1;
   int precision = 1;  // RTOW_F64_FAST; 0 = RTOW_F64_STRICT
   int kernel = 0;     // RTOW_KERNEL_AUTO
-  int builder = -1;   // -1: the context's default (RTOW_BUILDER env); 0 host SAH, 1 device (PLOC), 2 auto
+  int builder = -1;   // -1: the context's default (RTOW_BUILDER env); 0 host SAH, 1 device (binned SAH; RTOW_DEVICE_TREE=ploc|radix for the earlier trees), 2 auto
   bool binary_ppm = false;  // P6 (write_color runs on the device) instead of the reference's P3 text
   // OBJ input beyond the reference's (which reads shapes[0] only and throws on a face that is not a
   // triangle, src/main.cpp:115-133): every shape of the file, polygons fan-triangulated

@@ -146,7 +146,7 @@ def test_rtweekend_builder_flag(ctx):
     a = subprocess.run(args + ["--builder", "host"], capture_output=True, check=True)
     b = subprocess.run(args + ["--builder", "device"], capture_output=True, check=True)
     assert a.stdout == b.stdout and a.stdout.startswith(b"P3\n")
-    assert b"device (PLOC)" in b.stderr and b"host (SAH)" in a.stderr
+    assert b"built on the device" in b.stderr and b"built on the host (SAH)" in a.stderr
     bad = subprocess.run(args + ["--builder", "nope"], capture_output=True)
     assert bad.returncode != 0
 

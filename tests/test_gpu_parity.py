@@ -202,7 +202,8 @@ def test_rtweekend_binary_ppm_is_byte_identical_to_oracle(ctx):
         cfg = rtow.make_config(90, 60, 9, 3, 12, seed=77)
         ref, _ = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=4)
         assert r.stdout == orc.ppm_text(ref, 90, 60, 9)
-        assert b"Done in" in r.stderr
+        # the reference's stderr lines: the scanline countdown (its last state) right before "Done in" (src/render.cpp:154,188)
+        assert b"\rScanlines remaining: 0 " in r.stderr and r.stderr.index(b"Scanlines remaining") < r.stderr.index(b"\nDone in")
     # OBJ path (-l): suzanne
     r = subprocess.run([str(exe), "-l", str(GOLDEN / "suzanne.obj"), "-w", "64", "-a", str(16 / 9), "-s", "4",
                         "-t", "2", "-c", "20", "--seed", "5", "--precision", "strict"], capture_output=True, check=True)
