@@ -309,7 +309,7 @@ class Context:
         check(lib().rtow_scene_upload(self._h, C.byref(s)), "rtow_scene_upload")
 
     def set_builder(self, builder: int):
-        """BUILDER_HOST_SAH (default) or BUILDER_DEVICE_LBVH; applies from the next upload."""
+        """BUILDER_AUTO (default of a new context), BUILDER_HOST_SAH or BUILDER_DEVICE_LBVH; applies from the next upload."""
         check(lib().rtow_ctx_set_builder(self._h, builder), "rtow_ctx_set_builder")
 
     def debug_image(self, which: int) -> bytes:

@@ -122,6 +122,38 @@ def test_c2_whole_frame_fast_vs_strict_on_the_device(ctx):
     assert np.array_equal(part, a[240:248])
 
 
+@pytest.mark.parametrize("moving", [False, True])
+def test_c2_whole_frame_strict_equals_the_oracle_bit_for_bit(ctx, moving):
+    """configs[1] WHOLE: every one of the 960,000 pixels of the 1200x800 frame at the config's 100 spp, 50 bounces and
+    the bench's 10 streams — 96 M samples, 234 M ray segments — strict build against the oracle, f64 sums bit for bit
+    and the same segment count; static spheres (the bench's scene) and moving ones (the reference's default).  (The
+    strips above cover the same frame in pieces next to a fast render each; this is the statement without a selection:
+    some ten seconds of the box's 16 host threads per scene.)"""
+    scene = rtow.HostScene.cover(11, 1.5, moving)
+    W, H, spp, ns, depth, _, _ = C2
+    cfg = rtow.make_config(W, H, spp, ns, depth, seed=1, precision=rtow.F64_STRICT)
+    img, st = ctx.render(scene, cfg)
+    ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=16, accel=True)
+    assert st.kernel_used == rtow.KERNEL_GRID
+    assert st.samples == ost.samples == W * H * spp
+    assert st.segments == ost.segments
+    assert np.array_equal(img, ref), int((img != ref).sum())
+
+
+def test_c4_suzanne_whole_frame_strict_equals_the_oracle_bit_for_bit(ctx):
+    """configs[3]'s WHOLE 1920x1080 frame (every pixel, 20 bounces), at 32 of its 256 spp so that the oracle's share
+    stays within seconds: strict build against the oracle bit for bit.  (The full 256 spp are checked on the strips
+    below.)"""
+    scene = rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9)
+    W, H, _, _, depth, _, _ = C4
+    cfg = rtow.make_config(W, H, 32, 2, depth, seed=1, precision=rtow.F64_STRICT)
+    img, st = ctx.render(scene, cfg)
+    ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=16, accel=True)
+    assert st.kernel_used == rtow.KERNEL_BVH4
+    assert st.samples == ost.samples == W * H * 32 and st.segments == ost.segments
+    assert np.array_equal(img, ref), int((img != ref).sum())
+
+
 def test_c4_suzanne_strips_strict_bitwise_and_fast_within_tolerance(ctx):
     """configs[3]: suzanne.obj, 1920x1080, 256 spp, 20 bounces (the reference's default max_child_rays)."""
     scene = rtow.HostScene.obj(GOLDEN / "suzanne.obj", 16 / 9)
@@ -145,3 +177,25 @@ def test_c5_mesh100k_strips_strict_bitwise_and_fast_within_tolerance(ctx, mesh_o
         assert st.segments == ost.segments, r
         assert np.array_equal(img, ref), (r, int((img != ref).sum()))
         check_fast(fast, ref, 1024, ("C5 fast", r))
+
+
+def test_c5_mesh100k_whole_frame_strict_equals_the_oracle_with_both_builders(ctx, mesh_obj):
+    """configs[4]'s WHOLE 1920x1080 frame on the 96,800-triangle mesh, at 8 of its 1,024 spp (16.6 M samples: what the
+    oracle traces in seconds), strict build against the oracle bit for bit — with the tree AUTO takes for a mesh of this
+    size (built on the device: binned SAH, csrc/rtow_build.hip pass 3c) and with the host builder's."""
+    scene = rtow.HostScene.obj(mesh_obj, 16 / 9)
+    W, H, _, _, depth, _, _ = C5
+    cfg = rtow.make_config(W, H, 8, 2, depth, seed=3, precision=rtow.F64_STRICT)
+    ref, ost = orc.render(scene, cfg, orc.RNG_PHILOX, nthreads=16, accel=True)
+    used = []
+    for builder in (rtow.BUILDER_AUTO, rtow.BUILDER_HOST_SAH):
+        ctx.set_builder(builder)
+        try:
+            img, st = ctx.render(scene, cfg)
+            used.append(ctx.build_info().builder)
+        finally:
+            ctx.set_builder(rtow.BUILDER_AUTO)
+        assert st.kernel_used == rtow.KERNEL_BVH4
+        assert st.samples == ost.samples == W * H * 8 and st.segments == ost.segments
+        assert np.array_equal(img, ref), (builder, int((img != ref).sum()))
+    assert used == [rtow.BUILDER_DEVICE_LBVH, rtow.BUILDER_HOST_SAH]
