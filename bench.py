@@ -278,6 +278,7 @@ def load_pmc(workload, precision, kernel_used):
     """Derived PMC numbers of the committed profile of this workload/kernel (profiles/r02_pmc_*.json,
     written by scripts/pmc_summary.py from separate rocprofv3 --pmc passes), or None."""
     best = None
+    sha = kernel_source_sha()
     for f in sorted((ROOT / "profiles").glob("r*_pmc_*.json")):
         try:
             pj = json.loads(f.read_text())
@@ -287,7 +288,10 @@ def load_pmc(workload, precision, kernel_used):
         if not d or pj.get("workload") != workload or pj.get("precision") != precision or \
                 pj.get("kernel_used") != kernel_used:
             continue
-        best = dict(d, pmc_file=f"profiles/{f.name}", kernel_source_sha=pj.get("kernel_source_sha"))
+        cand = dict(d, pmc_file=f"profiles/{f.name}", kernel_source_sha=pj.get("kernel_source_sha"))
+        # the profile of THIS kernel source wins over older ones of the same workload (kept for the record)
+        if best is None or cand["kernel_source_sha"] == sha or best["kernel_source_sha"] != sha:
+            best = cand
     return best
 
 

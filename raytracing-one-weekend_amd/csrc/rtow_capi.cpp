@@ -77,6 +77,8 @@ namespace {
   } while (0)
 
 constexpr int kBlock = 256;      // STREAM kernel workgroup
+constexpr int kStreamTileMin = 64;  // STREAM kernel: from this many triangles on they are streamed through LDS tiles (below:
+                                    //   scalar loads — the kernel's real use, scenes of <= 16 primitives)
 constexpr int kBvhBlock = 512;   // BVH kernel workgroup (one LDS scene image per workgroup)
 constexpr unsigned kLdsLimit = 160u * 1024u;
 constexpr int kEventRing = 256;
@@ -281,6 +283,8 @@ struct Knobs {
                                   //   0 = Karras' radix tree (rounds 1-4); -1 = default: 16 up to 16,384 primitives, 8 above
   int device_tree = 2;            // RTOW_DEVICE_TREE=radix|ploc|sah: how the device builder makes its binary tree (0 / 1 / 2);
                                   //   sah = binned surface-area heuristic, top-down, level by level (pass 3c): the default
+  bool stream_scalar = false;     // RTOW_STREAM_SCALAR: the STREAM kernel's triangle loop through scalar loads at every size (A/B
+                                  //   against the LDS-tiled loop; rounds 1-5a)
   bool no_spec = false;           // RTOW_NO_SPEC: always the generic GRID kernel (A/B against the scene-class specialisations)
   int tail_bound = 0;             // RTOW_TAIL_BOUND (tests only): trips of the end-of-launch protocol before a wave gives up
                                   //   its samples (0 = the structural bound); a small value forces the RTOW_EHIP path
@@ -328,6 +332,7 @@ struct Knobs {
     sched_chunk_mesh = std::min(std::max(geti("RTOW_SCHED_CHUNK_MESH", 16), 0), 4096);
     tail_bound = std::max(geti("RTOW_TAIL_BOUND", 0), 0);
     no_spec = std::getenv("RTOW_NO_SPEC") != nullptr;
+    stream_scalar = std::getenv("RTOW_STREAM_SCALAR") != nullptr;
     if (const char *e = std::getenv("RTOW_PLOC_RADIUS")) ploc_radius = std::min(std::max(std::atoi(e), 0), 64);
     if (const char *e = std::getenv("RTOW_DEVICE_TREE"))
       device_tree = std::strcmp(e, "radix") == 0 ? 0 : (std::strcmp(e, "ploc") == 0 ? 1 : 2);
@@ -1293,6 +1298,12 @@ static int render_levels(rtow_ctx *c, const rtow_config_t *cfg, void *d_rgb_sums
       !c->knobs.bvh_block)
     block = 1024;
   unsigned lds_bytes = (image_kernel && image_bytes <= kLdsLimit) ? image_bytes : 0u;
+  scene.stream_tile_lds = 0u;
+  if (kernel == RTOW_KERNEL_BRUTE && scene.n_tri >= kStreamTileMin && !c->knobs.stream_scalar) {
+    // the tiled triangle loop of the STREAM kernel (csrc/rtow_trace_hit.h): two 3 KB tiles of LDS per wave
+    scene.stream_tile_lds = 2u * 32u * 96u;
+    lds_bytes = (unsigned)(block / 64) * scene.stream_tile_lds;
+  }
   int stack_bound = 0;
   if (kernel == RTOW_KERNEL_BVH4) {
     // One 1024-lane workgroup per CU.  LDS = [image, or the top of its tree][stack: K entries x 4 B per lane].

@@ -38,6 +38,7 @@ struct DevScene {
   const double *tri16;     // the same records at a stride of 16 doubles (128 B: a record is one 64-byte and one 32-byte
                            // aligned scalar load for the STREAM kernel; at 96 B it arrived in five or six pieces); NULL
                            // unless rtow_scene_upload built everything or the render asked for the STREAM kernel
+  uint32_t stream_tile_lds; // STREAM kernel: bytes of LDS every wave has for the tiled triangle loop (0: the scalar-load loop)
   const int32_t *prim_mat; // [n_prims]   material index by class-major id
   const DevMaterial *mats;
   int32_t n_sph, n_mov, n_tri, n_mats;

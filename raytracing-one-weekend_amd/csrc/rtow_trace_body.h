@@ -902,7 +902,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       if (tracing) best = closest_hit_reftree(sc, to_f64(ro), to_f64(rd), (double)rtime, nnode, nprim);
 #endif
     } else {
-      if (tracing) best = closest_hit_stream(sc, to_f64(ro), to_f64(rd), (double)rtime);
+      best = closest_hit_stream(sc, to_f64(ro), to_f64(rd), (double)rtime, tracing);  // (every lane: the tiled loop stages with all 64)
     }
 
     stamps.mark(RG_WALK, __ballot(tracing));
@@ -1078,7 +1078,7 @@ int RTOW_CAT(launch_trace_, RTOW_SUFFIX)(const TraceParams &p, int kernel, int g
   hipStream_t st = (hipStream_t)stream;
   const bool lds = lds_bytes > 0;
   switch (kernel) {
-    case 1: return launch_one<1, false, false>(p, grid, block, 0, st);
+    case 1: return launch_one<1, false, false>(p, grid, block, lds_bytes, st);  // (LDS: the tiled triangle loop's per-wave tiles)
     case 2: return lds ? launch_one<2, true, false>(p, grid, block, lds_bytes, st)
                        : launch_one<2, false, false>(p, grid, block, 0, st);
     case 3:

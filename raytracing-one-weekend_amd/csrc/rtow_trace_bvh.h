@@ -2,7 +2,7 @@
 // see that file for the execution model).  Scene-image reader, leaf tests and the threaded BVH walk.
 #pragma once
 // ---------------------------------------------------------- closest hit: BVH ---
-extern __shared__ __align__(16) unsigned char rtow_lds[];
+// (rtow_lds, the dynamic LDS block of the trace kernels, is declared in rtow_trace_math.h)
 
 // Scene image reader: LDS copy (ds_read_b128/b64) or the global blob (L1/L2).
 template <bool LDS>

@@ -145,3 +145,40 @@ __device__ __forceinline__ Vec3<T> refract(Vec3<T> I, Vec3<T> N, T eta) {
   return {T(0.0), T(0.0), T(0.0)};
 }
 
+// ---- typed access to LDS and global memory -------------------------------------------------------------------------
+// the dynamic LDS block of the trace kernels: a scene image (BVH / GRID), the top of the 4-wide tree and the traversal
+// stacks (BVH4), or the STREAM kernel's per-wave triangle tiles
+extern __shared__ __align__(16) unsigned char rtow_lds[];
+// LDS is addressed with 32-bit offsets through address-space-3 pointers, global memory through
+// address-space-1 pointers: with generic pointers the compiler merges the two sides of an
+// "in LDS or in global memory" choice into flat loads (and 64-bit address arithmetic).
+typedef float vf4 __attribute__((ext_vector_type(4)));      // native vectors: HIP's float4 class cannot be
+typedef uint32_t vu4 __attribute__((ext_vector_type(4)));   // read through an address-space pointer
+typedef double vd2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vh4 __attribute__((ext_vector_type(4)));   // four binary16 planes: the operands of v_fma_mix_f32
+#define RTOW_AS_LDS __attribute__((address_space(3)))
+#define RTOW_AS_GLB __attribute__((address_space(1)))
+// `off` IS the LDS address: the trace kernels have no static LDS, so the dynamic block (rtow_lds) starts at 0 —
+// checked on the host (trace_occupancy_*: hipFuncAttributes::sharedSizeBytes == 0).  Written as `rtow_lds + off` the
+// compiler kept a `v_add_u32 v, 0, v` per access (the symbol's address, resolved too late to fold): nine per node
+// step of the 4-wide walk.
+template <class T>
+__device__ __forceinline__ T lds_read(uint32_t off) {
+#ifdef RTOW_LDS_SYMBOL
+  return *(const RTOW_AS_LDS T *)((const RTOW_AS_LDS unsigned char *)rtow_lds + off);
+#else
+  return *(const RTOW_AS_LDS T *)(uintptr_t)off;
+#endif
+}
+template <class T>
+__device__ __forceinline__ void lds_write(uint32_t off, T v) {
+#ifdef RTOW_LDS_SYMBOL
+  *(RTOW_AS_LDS T *)((RTOW_AS_LDS unsigned char *)rtow_lds + off) = v;
+#else
+  *(RTOW_AS_LDS T *)(uintptr_t)off = v;
+#endif
+}
+template <class T>
+__device__ __forceinline__ T glb_read(const unsigned char *base, uint32_t off) {
+  return *(const RTOW_AS_GLB T *)((const RTOW_AS_GLB unsigned char *)base + off);
+}
