@@ -847,6 +847,34 @@ def main():
                         proj = W * H * 500 / ((b["step_ms_max"] + over) * 1e-3) / 1e6
                         b["projected_Msamples_per_s_with_handle"] = round(proj, 1)
                         b["projected_efficiency_with_handle"] = round(proj / (b["n_gpus"] * out["scaling_base"]["value"]), 4)
+        if world == 1 and a.workload == "cover" and spp == 100 and not a.no_scaling_base:
+            # A SEQUENCE of frames, two in flight (never `value`, which is one render at a time): two contexts on this
+            # device, each with its own stream, workspace and output, frames alternating between them, so that the next
+            # frame's workgroups are dispatched onto the CUs the draining frame leaves.  Each
+            # frame is a complete, separate render; the two outputs are compared bit for bit afterwards.
+            ctx_b = rtow.Context(local_rank)
+            ctx_b.upload(scene)
+            out_b = torch.zeros_like(local)
+            st_b = torch.cuda.Stream(dev)
+            pairs = ((ctx, local, stream), (ctx_b, out_b, st_b))
+            n_fif = max(a.steps, 2)
+            for k in range(4):
+                c2, o2, s2 = pairs[k % 2]
+                c2.render_device(cfg, o2.data_ptr(), s2.cuda_stream, False)
+            torch.cuda.synchronize(dev)
+            tf = time.perf_counter()
+            for k in range(n_fif):
+                c2, o2, s2 = pairs[k % 2]
+                c2.render_device(cfg, o2.data_ptr(), s2.cuda_stream, False)
+            torch.cuda.synchronize(dev)
+            ef = (time.perf_counter() - tf) / n_fif
+            out["two_frames_in_flight"] = {
+                "value": round(samples / ef / 1e6, 3), "unit": "Msamples/s", "ms_per_frame": round(ef * 1e3, 4), "frames": n_fif,
+                "frames_identical": bool(torch.equal(local, out_b)),
+                "note": "sustained rate of a sequence of frames alternating between two contexts / streams on one device; "
+                        "`value` is one render at a time",
+            }
+            ctx_b.close()
         if world == 1 and a.workload == "cover" and not a.spp and not a.no_other_configs:
             out["other_configs"] = [other_config(n, a, dev, precision, s)
                                     for n, s in (("moving", 4), ("suzanne", 3), ("mesh100k", 2))]

@@ -88,6 +88,9 @@ def compact_line(details, details_path=None):
                                 "over_kernel_ms": _get(mh, "rgb8", "over_kernel_ms"),
                                 "over_rtow_render_rgb8": _get(mh, "rgb8", "over_rtow_render_rgb8")}
     line["other"] = _other(details)
+    fif = _get(details, "two_frames_in_flight", "value")
+    if fif is not None and line["other"] is not None:
+        line["other"]["cover_two_frames_in_flight"] = fif  # (a sequence of frames, two in flight: never `value`)
     line["details"] = details_path
     return line
 
