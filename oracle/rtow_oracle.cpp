@@ -169,135 +169,88 @@ inline void philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
   out[3] = c3;
 }
 
-// One request = one Philox block = four 32-bit words w0..w3 (the layouts are restated at each
-// request_*() below and pinned word by word in tests/test_oracle_units.py):
-//   first block of a sample : u, v, time = top 21 bits of w0, w1, w2 (* 2^-21); first lens-disk
-//                             candidate = w3 and the 11+11+10 low bits of w0..w2 (* 2^-32 each)
-//   further lens-disk block : two candidates (w0, w1), (w2, w3), 32 bits per coordinate
-//   first block of a bounce : a unit-ball candidate from (w0, w1) — x, y = top 21 bits, z = the
-//                             11+10 low bits left over — and EITHER the dielectric coin w2 * 2^-32 (a bounce that
-//                             draws one) OR a second candidate from (w2, w3) (every other bounce; round 4)
-//   further scatter block   : two unit-ball candidates, (w0, w1) and (w2, w3)
+// One request = one Philox block = four 32-bit words w0..w3 = everything the request needs (round 5: no request draws
+// a second block; the layouts are pinned word by word in tests/test_oracle_units.py and restated by the device in
+// raytracing-one-weekend_amd/csrc/rtow_trace_rng.h):
+//   request 0 of a sample     : u, v, time = top 21 bits of w0, w1, w2 (* 2^-21); the two 32-bit uniforms of the lens
+//                               point = w3 and the 11+11+10 low bits of w0..w2
+//   request 1 + b (bounce b)  : z = top 24 bits of w0, azimuth = top 24 bits of w1, three radius uniforms = the two
+//                               halves of w2 and the low half of w3 (16 bits each), dielectric coin (32 bits) = the high
+//                               half of w3 and the low bytes of w0, w1
+// The reference draws its lens point and its "unit vector" by REJECTION (random_in_unit_disk, random_in_unit_sphere:
+// src/random-utils.cpp:23-41).  This policy — the device's — draws the same two DISTRIBUTIONS directly, one block per
+// request (random_in_unit_disk / random_in_unit_sphere overloads below): uniform on the unit disk as (sqrt(U1), 2 pi U2)
+// in polar coordinates; uniform in the positive octant of the unit ball (what the loop over [0,1)^3 returns) as radius
+// max(U1, U2, U3) times a direction uniform on the octant of the sphere (z = U4, azimuth (pi/2) U5).  The reference's own
+// loops are the MtGlobal policy's, which reproduces the reference's images byte for byte (tests/test_oracle_golden.py);
+// what ties the two policies together is the statistical test T3 (tests/test_oracle_units.py), as it always was.
 struct PhiloxDraw {
   uint64_t seed = 0;
   uint32_t pixel = 0, sample = 0, r = 0;
   uint64_t ndraws = 0;
   double buf[3];
   int have = 0, pos = 0;
-  double stash_time = 0.0;   // third value of the jitter request
-  double stash_disk[2] = {0.0, 0.0};  // lens-disk candidate waiting in a block already drawn
-  int disk_k = 0;            // lens-disk candidates handed out in this sample
-  double stash_scat[3] = {0.0, 0.0, 0.0};  // unit-ball candidate waiting in a block already drawn
-  int scat_k = 0;            // unit-ball candidates handed out in this bounce
-  bool coin_peeked = false;  // the next scatter request re-uses the block the coin came from
+  double stash_time = 0.0;     // third value of the jitter request
+  uint32_t lens_a = 0, lens_b = 0;  // the lens point's two 32-bit uniforms (same block)
+  uint32_t w[4] = {0, 0, 0, 0};     // the words of the bounce's block (request_scatter)
   void begin_sample(uint32_t p, uint32_t s) {
     pixel = p;
     sample = s;
     r = 0;
     have = pos = 0;
-    disk_k = 0;
-    coin_peeked = false;
   }
   void block(uint32_t req, uint32_t o[4]) const {
     uint32_t ctr[4] = {req, sample, pixel, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     philox4x32(ctr, key, o, kPhiloxRounds);
   }
-  // The first block of a sample: pixel jitter and shutter time, 21 bits each (the top bits of words
-  // 0..2), and the FIRST lens-disk candidate, 32 bits per coordinate (word 3 and the 11+11+10 low
-  // bits left in words 0..2).
+  // The first block of a sample: pixel jitter and shutter time, 21 bits each (the top bits of words 0..2), and the two
+  // uniforms of the lens point, 32 bits each (word 3 and the 11+11+10 low bits left in words 0..2).
   void request_jitter() {
     uint32_t o[4];
     block(r++, o);
-    const double s21 = 0x1p-21, s32 = 0x1p-32;
+    const double s21 = 0x1p-21;
     buf[0] = (double)(o[0] >> 11) * s21;
     buf[1] = (double)(o[1] >> 11) * s21;
     stash_time = (double)(o[2] >> 11) * s21;
-    stash_disk[0] = (double)o[3] * s32;
-    stash_disk[1] = (double)((o[0] & 0x7ffu) | ((o[1] & 0x7ffu) << 11) | ((o[2] & 0x3ffu) << 22)) * s32;
-    disk_k = 0;
+    lens_a = o[3];
+    lens_b = (o[0] & 0x7ffu) | ((o[1] & 0x7ffu) << 11) | ((o[2] & 0x3ffu) << 22);
     have = 2;
     pos = 0;
   }
-  // Lens-disk candidates (two values each, 32 bits per value): #1 came with the jitter block; every
-  // further block carries two candidates, (w0, w1) and (w2, w3).
-  void request_disk() {
-    if (disk_k == 0 || (disk_k & 1) == 0) {  // #1, or the second candidate of a block
-      buf[0] = stash_disk[0];
-      buf[1] = stash_disk[1];
-    } else {
-      uint32_t o[4];
-      block(r++, o);
-      const double s32 = 0x1p-32;
-      buf[0] = (double)o[0] * s32;
-      buf[1] = (double)o[1] * s32;
-      stash_disk[0] = (double)o[2] * s32;
-      stash_disk[1] = (double)o[3] * s32;
-    }
-    ++disk_k;
-    have = 2;
-    pos = 0;
-  }
+  void request_disk() {}  // (the lens point's uniforms came with the jitter block)
   void request_time() {
     buf[0] = stash_time;
     have = 1;
     pos = 0;
   }
-  // Unit-ball candidates: 21 bits per coordinate, one candidate per pair of words — x and y are
-  // the top 21 bits of the two words, z the 11 + 10 low bits left over.  The first block of a
-  // bounce carries a candidate (words 0, 1) and the dielectric coin (word 2, 32 bits) or a second candidate; every
-  // further block carries two candidates, (w0, w1) and (w2, w3).
-  static void ball_from_pair(uint32_t lo, uint32_t hi, double out[3]) {
-    const double s21 = 0x1p-21;
-    out[0] = (double)(lo >> 11) * s21;
-    out[1] = (double)(hi >> 11) * s21;
-    out[2] = (double)((lo & 0x7ffu) | ((hi & 0x3ffu) << 11)) * s21;
+  void begin_scatter() {}
+  static double coin_of(const uint32_t o[4]) {
+    return (double)(((o[3] >> 16) << 16) | ((o[0] & 0xffu) << 8) | (o[1] & 0xffu)) * 0x1p-32;
   }
-  void begin_scatter() { scat_k = 0; }
-  void request_coin() {  // peek at the block the first scatter candidate will use
+  void request_coin() {  // peek at the bounce's block (request_scatter consumes it)
     uint32_t o[4];
     block(r, o);
-    buf[0] = (double)o[2] * 0x1p-32;
+    buf[0] = coin_of(o);
     have = 1;
     pos = 0;
-    coin_peeked = true;
   }
-  // The first block of a bounce: candidate #1 from words (0, 1); words (2, 3) are the dielectric coin (word 2) when the
-  // bounce drew one, and otherwise candidate #2 (round 4: a bounce without a coin — Lambertian, Metal, total
-  // reflection — finds two candidates in its first block).  Every further block: two candidates, (0, 1) and (2, 3).
-  bool first_has_second = false;
-  void request_scatter() {
-    if (scat_k == 0) {
-      uint32_t o[4];
-      block(r++, o);
-      ball_from_pair(o[0], o[1], buf);
-      first_has_second = !coin_peeked;
-      if (first_has_second) ball_from_pair(o[2], o[3], stash_scat);
-    } else if (scat_k == 1 && first_has_second) {
-      buf[0] = stash_scat[0];
-      buf[1] = stash_scat[1];
-      buf[2] = stash_scat[2];
-    } else if (((scat_k - (first_has_second ? 2 : 1)) & 1) == 0) {  // the first candidate of a further block
-      uint32_t o[4];
-      block(r++, o);
-      ball_from_pair(o[0], o[1], buf);
-      ball_from_pair(o[2], o[3], stash_scat);
-    } else {
-      buf[0] = stash_scat[0];
-      buf[1] = stash_scat[1];
-      buf[2] = stash_scat[2];
-    }
-    ++scat_k;
-    have = 3;
-    pos = 0;
-    coin_peeked = false;
-  }
+  void request_scatter() { block(r++, w); }
   double canonical() {
     if (pos >= have) std::abort();  // a draw outside a request: oracle bug
     ++ndraws;
     return buf[pos++];
   }
 };
+
+// sin on [0, pi/2]: x (c0 + x^2 (c1 + x^2 (c2 + x^2 (c3 + x^2 c4)))), a degree-9 Chebyshev fit, |error| < 7e-9 — the
+// device's polynomial, same coefficients, same order of operations (rtow_trace_rng.h, sin_quarter); cos x = sin(pi/2 - x)
+inline double sin_quarter(double x) {
+  const double x2 = x * x;
+  return x * (0x1.ffffffdb33084p-1 +
+              x2 * (-0x1.555549a9260fdp-3 + x2 * (0x1.110eb1f04c8ffp-7 + x2 * (-0x1.9f6d0201a288bp-13 + x2 * 0x1.5da8d4e70fe23p-19))));
+}
+constexpr double kHalfPi = 1.5707963267948966;
 
 // src/random-utils.cpp:11-13 — uniform_real_distribution{a,b}: canonical*(b-a)+a
 template <class R>
@@ -324,6 +277,20 @@ inline V3 random_in_unit_sphere(R &rng) {
     return v;
   }
 }
+// The Philox policy's direct form of the same distribution (uniform in the positive octant of the unit ball): radius =
+// the largest of three uniforms, direction uniform on the octant of the sphere.  One block, no loop.
+inline V3 random_in_unit_sphere(PhiloxDraw &rng) {
+  rng.request_scatter();
+  rng.ndraws += 5;
+  const uint32_t *o = rng.w;
+  const double z = (double)(o[0] >> 8) * 0x1p-24;
+  const double phi = (double)(o[1] >> 8) * (0x1p-24 * kHalfPi);
+  const uint32_t rm = std::max(std::max(o[2] & 0xffffu, o[2] >> 16), o[3] & 0xffffu);
+  const double r = (double)rm * 0x1p-16;
+  const double sn = sin_quarter(phi), cs = sin_quarter(kHalfPi - phi);
+  const double rs = r * std::sqrt(1.0 - z * z);
+  return {rs * cs, rs * sn, r * z};
+}
 template <class R>
 inline V3 random_unit_vector(R &rng) {
   return random_in_unit_sphere(rng);
@@ -341,6 +308,21 @@ inline V3 random_in_unit_disk(R &rng) {
     if (dot(p, p) >= 1) continue;
     return p;
   }
+}
+
+// The Philox policy's direct form: uniform on the unit disk in polar coordinates (radius sqrt(U1), angle 2 pi U2 — the
+// top two bits of U2 choose the quadrant, the other thirty the angle inside it).
+inline V3 random_in_unit_disk(PhiloxDraw &rng) {
+  rng.ndraws += 2;
+  const uint32_t b = rng.lens_b;
+  const double rho = std::sqrt((double)rng.lens_a * 0x1p-32);
+  const double th = (double)(b & 0x3fffffffu) * (0x1p-30 * kHalfPi);
+  const double sn = sin_quarter(th), cs = sin_quarter(kHalfPi - th);
+  const uint32_t q = b >> 30;
+  const double cx = (q & 1u) ? sn : cs, sy = (q & 1u) ? cs : sn;
+  const double px = rho * ((q == 1u || q == 2u) ? -cx : cx);
+  const double py = rho * (q >= 2u ? -sy : sy);
+  return {px, py, 0};
 }
 
 // ------------------------------------------------------------------ model ---
@@ -1107,37 +1089,32 @@ void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4
 }
 int orc_philox_rounds(void) { return kPhiloxRounds; }
 
-// value k of request `request` of kind 0 = jitter (u, v, time), 1 = disk (y, x),
-// 2 = scatter (x, y, z, coin)
+// value k of request `request`: kind 0 = the block of a new sample (k = 0, 1 jitter u, v; 2 shutter time; 3, 4 the
+// lens point x, y), kind 2 = the block of a bounce (k = 0..2 the point of the unit ball x, y, z; 3 the dielectric coin);
+// the raw words of the block: orc_philox4x32 with counter (request, sample, pixel, 0)
 double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t request, int kind,
                           int k) {
   PhiloxDraw g;
   g.seed = seed;
   g.begin_sample(pixel, sample);
   g.r = request;
-  if (kind == 0) {  // k = 0, 1: jitter; 2: time; 3, 4: the first lens-disk candidate
+  if (kind == 0) {
     g.request_jitter();
-    if (k >= 3) return g.stash_disk[k - 3];
+    if (k >= 3) {
+      const V3 p = random_in_unit_disk(g);
+      return k == 3 ? p.x : p.y;
+    }
     return k == 2 ? g.stash_time : g.buf[k];
   }
-  if (kind == 1) {  // a later lens-disk block: k = 0, 1 first candidate; 2, 3 second candidate
-    g.disk_k = 1;
-    g.request_disk();
-    return k < 2 ? g.buf[k] : g.stash_disk[k - 2];
-  }
-  if (kind == 2) {  // first unit-ball block of a bounce: k = 0..2 candidate, 3 the coin, 4..6 the second candidate of a
-    if (k == 3) {   // bounce without a coin
+  if (kind == 2) {
+    if (k == 3) {
       g.request_coin();
       return g.buf[0];
     }
-    g.request_scatter();
-    return k < 3 ? g.buf[k] : g.stash_scat[k - 4];
+    const V3 v = random_in_unit_sphere(g);
+    return k == 0 ? v.x : (k == 1 ? v.y : v.z);
   }
-  // kind 3: a later unit-ball block: k = 0..2 first candidate, 3..5 second candidate
-  g.scat_k = 1;
-  g.first_has_second = false;
-  g.request_scatter();
-  return k < 3 ? g.buf[k] : g.stash_scat[k - 3];
+  return std::nan("");
 }
 
 // lots_of_balls(), src/main.cpp:23-83.

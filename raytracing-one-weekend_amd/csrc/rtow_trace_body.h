@@ -39,17 +39,11 @@
 //     equal to a few ulps — and need neither the stack nor the unwind loop (+6.2 %).  A path
 //     that ends black contributes an exact zero.
 //   * RNG: Philox4x32-7 in REQUESTS, one block each, counter (request, sample, pixel,
-//     0), key = seed.  The first block of a sample carries the pixel jitter and the shutter
-//     time (21 bits each) AND the first lens-disk candidate (32 bits per coordinate); a
-//     further lens-disk block carries two candidates.  Unit-ball candidates have 21 bits per
-//     coordinate, one candidate per pair of words: the first block of a bounce carries a candidate in
-//     words 0, 1 and either the dielectric coin (word 2, 32 bits) or — for a bounce that draws no coin —
-//     a second candidate in words 2, 3 (round 4); every further block two candidates.
-//     Whole blocks per request keep the rejection loops free of per-lane parity divergence;
-//     Philox is a large share of the kernel's VALU time, so blocks are not wasted (packing the
-//     lens candidates removed ~1.9 of the ~4 blocks a wave spends per trip on new camera rays:
-//     +3.1 %; two unit-ball candidates per block cut the scatter loop from ~5.9 to ~3.8 blocks
-//     per trip: +2.0 %).
+//     0), key = seed.  Request 0 of a sample carries the pixel jitter and the shutter time (21 bits each) and the two
+//     32-bit uniforms of the lens point; request 1 + b everything bounce b draws: the five uniforms of its point in the
+//     unit ball and the dielectric coin.  EXACTLY one block per request: the reference's rejection loops
+//     (src/random-utils.cpp:23-41) are replaced by direct samplers of the same distributions (rtow_trace_rng.h, round 5)
+//     — a wave used to run them as long as its unluckiest lane, 2.35 further block evaluations per trip for 7 lanes each.
 //
 // In the strict build (-ffp-contract=off) every expression below has the operand
 // order of the reference expression it restates, f64 sqrt and division are the
@@ -221,22 +215,14 @@ __device__ __forceinline__ void camera_ray(const TraceParams &P, Rng &g, uint32_
                                            uint32_t gi, V3 &ro, V3 &rd, real &rtime) {
   g.r = 0u;
   const int from_top_i = P.H - (int)gi - 1;
-  real ju, jv, jt, c0, c1;
-  rng_jitter(g, k0, k1, ju, jv, jt, c0, c1);
+  uint32_t o0, o1, o2, o3;
+  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
+  real ju, jv, jt, px, py;
+  jitter_from_block(o0, o1, o2, ju, jv, jt);
+  lens_from_block(o0, o1, o2, o3, px, py);
   const real u = fast_div((real)(int)j + ju, (real)(P.W - 1));
   const real v = fast_div((real)from_top_i + jv, (real)(P.H - 1));
-  real py = c0 * (real(1.0) - real(-1.0)) + real(-1.0);
-  real px = c1 * (real(1.0) - real(-1.0)) + real(-1.0);
-  while (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) {
-    real a0, b0, a1, b1;
-    rng_disk2(g, k0, k1, a0, b0, a1, b1);
-    py = a0 * (real(1.0) - real(-1.0)) + real(-1.0);
-    px = b0 * (real(1.0) - real(-1.0)) + real(-1.0);
-    if (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) {
-      py = a1 * (real(1.0) - real(-1.0)) + real(-1.0);
-      px = b1 * (real(1.0) - real(-1.0)) + real(-1.0);
-    }
-  }
   // camera block: wave-uniform scalar loads (origin u v horizontal vertical llc | lens t0 t1)
 #ifdef RTOW_REAL_F32
   const RTOW_CONST float *cm = (const RTOW_CONST float *)P.cam32;
@@ -256,10 +242,9 @@ __device__ __forceinline__ void camera_ray(const TraceParams &P, Rng &g, uint32_
 // direction, or absorbed.  The first unit-ball candidate of the bounce comes with the dielectric coin.
 __device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, int kind, real m_fuzz, real m_ir, V3 rd,
                                             V3 normal, bool front, V3 &dir) {
-  real coin;
-  BallCand c1, c2;
-  rng_scatter_first(g, k0, k1, coin, c1, c2);
-  bool used_coin = false;
+  uint32_t o0, o1, o2, o3;
+  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+  g.r += 1u;
   V3 dirbase = {0, 0, 0};
   if (kind == 2) {
     const real ir = m_ir;
@@ -269,28 +254,19 @@ __device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, in
     const real ratio = front ? fast_rcp(ir) : ir;
     bool refl = ratio * sin_theta > real(1.0);
     if (!refl) {
-      used_coin = true;
       real r0 = fast_div(real(1.0) - ratio, real(1.0) + ratio);
       r0 = r0 * r0;
       const real x = real(1.0) - cos_theta;
       const real x2 = x * x;
       const real R = r0 + (real(1.0) - r0) * (x2 * x2 * x);
-      refl = R > coin;
+      refl = R > coin_from_block(o0, o1, o3);
     }
     dirbase = refl ? reflect(unit, normal) : refract(unit, normal, ratio);
   } else if (kind == 1) {
     dirbase = reflect(rd, normal);
   }
-  // random_unit_vector(): reject candidates outside the unit ball (random-utils.cpp:23-33).  The first block holds
-  // a second candidate when the bounce drew no coin; every further block two.  (Exact integer test, rtow_trace_rng.h.)
-  BallCand cand = c1;
-  if (ball_outside(cand) && !used_coin) cand = c2;
-  while (ball_outside(cand)) {
-    BallCand ca, cb;
-    rng_scatter2i(g, k0, k1, ca, cb);
-    cand = ball_outside(ca) ? cb : ca;
-  }
-  const V3 rnd = ball_point(cand);
+  // random_unit_vector() (random-utils.cpp:31-33): the point of the unit ball's positive octant, un-normalised
+  const V3 rnd = ball_from_block(o0, o1, o2, o3);
   bool absorbed = false;
   if (kind == 0) {
     absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
@@ -720,12 +696,14 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       }
 
     }
-    // The random-number window — first Philox block, jitter / dielectric decision, rejection loop — is dense integer
+    // The random-number window — the request's one Philox block and what is decoded from it at once — is dense integer
     // and f64 arithmetic with no memory access: it runs at the LOWEST issue priority, so that of the four waves of a SIMD
     // those in a latency-bound stage (cell lists, the DDA's cell words, hit records) issue first and the arithmetic of
     // this window fills the gaps they leave (stage_prio, rtow_trace_math.h; measured in DESIGN.md §4.7 d13).
     stage_prio<kPrioRng>();
-    // first block of the sample / of the bounce
+    // THE block of the request: request 0 of a new sample (jitter, shutter time, lens point) or request 1 + bounce of
+    // a scattered ray (point of the unit ball, dielectric coin).  One evaluation serves both kinds of lanes, and no
+    // request draws a second block (rtow_trace_rng.h: the reference's rejection loops are direct samplers here).
     uint32_t o0 = anyv(0u), o1 = anyv(0u), o2 = anyv(0u), o3 = anyv(0u);
     if (do_regen) g.r = 0u;
     if (do_regen || do_scat) {
@@ -735,23 +713,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     if constexpr (STAMPS) {  // wave-level count of block evaluations: the first active lane reports
       if (__ballot(do_regen || do_scat) != 0ull) stamps.blocks += 1;
     }
-    real ju = anyv(real(0)), jv = anyv(real(0)), jt = anyv(real(0)), px = anyv(real(0)), py = anyv(real(0));  // new sample: jitter, shutter time, lens-disk candidate
-    V3 rnd = anyv3(), dirbase = anyv3();          // bounce: unit-ball candidate, direction before the fuzz term
-    BallCand cand = {anyv(0u), anyv(0u), anyv(0u)};  // ... as its 21-bit integers while it may still be rejected
-    bool rej = false;
-    if (do_regen) {
-      // disk sample: y draws first (random-utils.cpp:36).  The first candidate comes with the jitter block.
-      real c0, c1;
-      jitter_from_block(o0, o1, o2, o3, ju, jv, jt, c0, c1);
-      py = c0 * (real(1.0) - real(-1.0)) + real(-1.0);
-      px = c1 * (real(1.0) - real(-1.0)) + real(-1.0);
-      rej = px * px + py * py + real(0.0) * real(0.0) >= real(1.0);
-    }
+    V3 dirbase = anyv3();  // bounce: direction before the fuzz term
     if (do_scat) {
-      // the first unit-ball candidate of the bounce comes with the dielectric coin (word 2)
-      const real coin = (real)o2 * real(0x1p-32);
-      cand = ball_ints(o0, o1);
-      bool used_coin = false;  // src/common-model.cpp:53-54: the coin is drawn only if refraction is possible
       if (kind == 2) {
         const real ir = m_ir;
         const V3 unit = normalize(rd);
@@ -759,64 +722,25 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
         const real sin_theta = fast_sqrt(real(1.0) - cos_theta * cos_theta);
         const real ratio = front ? fast_rcp(ir) : ir;
         bool refl = ratio * sin_theta > real(1.0);
-        if (!refl) {
-          used_coin = true;
+        if (!refl) {  // src/common-model.cpp:53-54: the coin is drawn only if refraction is possible
           real r0 = fast_div(real(1.0) - ratio, real(1.0) + ratio);
           r0 = r0 * r0;
           const real x = real(1.0) - cos_theta;
           const real x2 = x * x;
           const real R = r0 + (real(1.0) - r0) * (x2 * x2 * x);
-          refl = R > coin;
+          refl = R > coin_from_block(o0, o1, o3);
         }
         dirbase = refl ? reflect(unit, normal) : refract(unit, normal, ratio);
       } else if (kind == 1) {
         dirbase = reflect(rd, normal);
       }
-      rej = ball_outside(cand);
-      // a bounce that drew no coin (Lambertian, Metal, total reflection) finds a SECOND candidate in words 2, 3 of its
-      // first block (round 4; oracle/rtow_oracle.cpp PhiloxDraw::request_scatter): half a rejection round less per
-      // trip for ten instructions
-      if (rej && !used_coin) {
-        cand = ball_ints(o2, o3);
-        rej = ball_outside(cand);
-      }
-    }
-    // rejection sampling (random-utils.cpp:23-41): every further block carries two candidates
-    uint32_t rej_trips = 0u;  // (diagnostic build only)
-    while (rej) {
-      if constexpr (STAMPS) ++rej_trips;
-      philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-      g.r += 1u;
-      if (do_regen) {
-        const real s32 = real(0x1p-32);
-        py = ((real)o0 * s32) * (real(1.0) - real(-1.0)) + real(-1.0);
-        px = ((real)o1 * s32) * (real(1.0) - real(-1.0)) + real(-1.0);
-        if (px * px + py * py + real(0.0) * real(0.0) >= real(1.0)) {
-          py = ((real)o2 * s32) * (real(1.0) - real(-1.0)) + real(-1.0);
-          px = ((real)o3 * s32) * (real(1.0) - real(-1.0)) + real(-1.0);
-        }
-        rej = px * px + py * py + real(0.0) * real(0.0) >= real(1.0);
-      } else {
-        const BallCand ca = ball_ints(o0, o1), cb = ball_ints(o2, o3);
-        cand = ball_outside(ca) ? cb : ca;
-        rej = ball_outside(cand);
-      }
     }
     stage_prio<kPrioStage>();
-    if (do_scat) rnd = ball_point(cand);  // only the accepted candidate becomes a vector
-    if constexpr (STAMPS) {  // what the wave ran: as many trips as its unluckiest lane needed
-      uint32_t mx = rej_trips, sum = rej_trips;
-      for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t m2 = (uint32_t)__shfl_xor((int)mx, off), s2 = (uint32_t)__shfl_xor((int)sum, off);
-        mx = mx > m2 ? mx : m2;
-        sum += s2;
-      }
-      stamps.blocks += mx;
-      stamps.block_lanes += sum;
-    }
     if (do_regen) {
       // src/render.cpp:158-159, src/common-model.cpp:156-167
       const int from_top_i = P.H - (int)gi - 1;
+      real ju, jv, jt;  // pixel jitter, shutter time
+      jitter_from_block(o0, o1, o2, ju, jv, jt);
 #ifdef RTOW_FAST_MATH
       // the divisors are constants of the launch: their reciprocals come from the host (two scalar loads from the
       // kernel-argument segment beside the camera block's) instead of two v_rcp_f64 + refinement per new sample
@@ -835,6 +759,8 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       cdptr cm = (cdptr)(const double *)P.cam;
 #endif
       const real lens = cm[18], ct0 = cm[19], ct1 = cm[20];
+      real px, py;  // random_in_unit_disk (src/common-model.cpp:157)
+      lens_from_block(o0, o1, o2, o3, px, py);
       const real rdx = lens * px, rdy = lens * py;
       const V3 offset = V3{cm[3], cm[4], cm[5]} * rdx + V3{cm[6], cm[7], cm[8]} * rdy;
       const V3 from = V3{cm[0], cm[1], cm[2]} + offset;
@@ -853,6 +779,7 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       bool absorbed = false;
       // (the new direction is written over the old one in both branches; an absorbed path — black, src/render.cpp:120 —
       // starts a new sample in the next trip and never reads it)
+      const V3 rnd = ball_from_block(o0, o1, o2, o3);  // random_unit_vector() (src/common-model.cpp:16,26,58)
       if (kind == 0) {
         absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
                    rabs(normal.z - rnd.z) < real(1e-8);

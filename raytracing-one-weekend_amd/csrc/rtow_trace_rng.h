@@ -37,76 +37,69 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
   o3 = c3;
 }
 
-// One request = one block (w0..w3); see oracle/rtow_oracle.cpp, struct PhiloxDraw.
-// First block of a sample: pixel jitter + shutter time, 21 bits each (top bits of words 0..2), and
-// the first lens-disk candidate, 32 bits per coordinate (word 3; the 11+11+10 low bits of words 0..2).
-__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, real &u, real &v,
-                                                  real &t, real &da, real &db) {
-  const real s21 = real(0x1p-21), s32 = real(0x1p-32);
+// One request = one block (w0..w3) = everything the request needs: no request ever draws a second block (round 5).
+// The layouts are restated in oracle/rtow_oracle.cpp, struct PhiloxDraw, and pinned word by word in
+// tests/test_oracle_units.py.
+//
+// The reference draws its random points by REJECTION: random_in_unit_disk() and random_in_unit_sphere()
+// (src/random-utils.cpp:23-41) loop until a point of the square / cube lies inside, accepting pi/4 and pi/6 of their
+// candidates.  On a 64-lane wave that loop runs as long as the wave's unluckiest lane: with two candidates per block
+// 2.35 further block evaluations per trip for 7 lanes each (profiles/r05_stamps.log), 9-11 % of the cover scene's
+// run time (profiles/r05_ab_no_rejection_ceiling.log).  The device — and the oracle's Philox policy with it — draws
+// the SAME DISTRIBUTIONS directly instead:
+//   unit disk (lens)     radius = sqrt(U1), angle = 2 pi U2: uniform on the disk;
+//   unit ball, positive  radius = max(U1, U2, U3) (distribution function r^3), direction uniform on the octant of the
+//   octant (scatter)     sphere: z = U4, azimuth = (pi/2) U5 (Archimedes: the area of a zone depends on its height
+//                        alone) — what the reference's loop over [0,1)^3 returns, un-normalised, as its "unit vector"
+// with sine and cosine of the azimuth from ONE fixed polynomial (below), evaluated in the same order by the oracle, so
+// the strict build stays bit-identical to it.  The reference's own loops live on in the oracle's mt19937 policy, which
+// reproduces its images byte for byte; the statistical test between the two policies (tests/test_oracle_units.py, T3)
+// is what ties this stream to the reference's, as before.
+//
+// sin on [0, pi/2]:  x (c0 + x^2 (c1 + x^2 (c2 + x^2 (c3 + x^2 c4)))), a degree-9 Chebyshev fit, |error| < 7e-9
+// (an un-normalised direction offset of 2^-21 granularity took this place before); cos x = sin(pi/2 - x).
+__device__ __forceinline__ real sin_quarter(real x) {
+  const real x2 = x * x;
+  return x * (real(0x1.ffffffdb33084p-1) +
+              x2 * (real(-0x1.555549a9260fdp-3) +
+                    x2 * (real(0x1.110eb1f04c8ffp-7) + x2 * (real(-0x1.9f6d0201a288bp-13) + x2 * real(0x1.5da8d4e70fe23p-19)))));
+}
+constexpr double kHalfPi = 1.5707963267948966;  // the binary64 nearest pi / 2
+
+// First block of a sample (request 0): pixel jitter and shutter time, 21 bits each (the top bits of words 0..2), and the
+// two 32-bit uniforms of the lens point: word 3, and the 11 + 11 + 10 low bits left over in words 0..2.
+__device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint32_t o2, real &u, real &v, real &t) {
+  const real s21 = real(0x1p-21);
   u = (real)(o0 >> 11) * s21;
   v = (real)(o1 >> 11) * s21;
   t = (real)(o2 >> 11) * s21;
-  da = (real)o3 * s32;
-  db = (real)((o0 & 0x7ffu) | ((o1 & 0x7ffu) << 11) | ((o2 & 0x3ffu) << 22)) * s32;
 }
-__device__ __forceinline__ void rng_jitter(Rng &g, uint32_t k0, uint32_t k1, real &u, real &v, real &t, real &da,
-                                           real &db) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
-  jitter_from_block(o0, o1, o2, o3, u, v, t, da, db);
+// random_in_unit_disk (src/random-utils.cpp:34-41), directly: radius sqrt(word 3 * 2^-32); angle from the 32 low bits —
+// their top two choose the quadrant, the other thirty the angle inside it
+__device__ __forceinline__ void lens_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, real &px, real &py) {
+  const uint32_t b = (o0 & 0x7ffu) | ((o1 & 0x7ffu) << 11) | ((o2 & 0x3ffu) << 22);
+  const real rho = fast_sqrt((real)o3 * real(0x1p-32));
+  const real th = (real)(b & 0x3fffffffu) * real(0x1p-30 * kHalfPi);
+  const real sn = sin_quarter(th), cs = sin_quarter(real(kHalfPi) - th);
+  const uint32_t q = b >> 30;
+  const real cx = (q & 1u) ? sn : cs, sy = (q & 1u) ? cs : sn;
+  px = rho * ((q == 1u || q == 2u) ? -cx : cx);
+  py = rho * (q >= 2u ? -sy : sy);
 }
-// a further lens-disk block: two candidates, (w0, w1) and (w2, w3), 32 bits per coordinate
-__device__ __forceinline__ void rng_disk2(Rng &g, uint32_t k0, uint32_t k1, real &a0, real &b0, real &a1, real &b1) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
-  const real s32 = real(0x1p-32);
-  a0 = (real)o0 * s32;
-  b0 = (real)o1 * s32;
-  a1 = (real)o2 * s32;
-  b1 = (real)o3 * s32;
+// The block of a bounce (request 1 + bounce): z = the top 24 bits of word 0, azimuth = the top 24 bits of word 1, the
+// three radius uniforms = the halves of word 2 and the low half of word 3 (16 bits each), and the dielectric coin (32
+// bits) = the high half of word 3 and the low bytes of words 0 and 1.
+// random_in_unit_sphere (src/random-utils.cpp:23-29), directly; returned un-normalised like the reference's
+// "random_unit_vector" (:31-33)
+__device__ __forceinline__ V3 ball_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+  const real z = (real)(o0 >> 8) * real(0x1p-24);
+  const real phi = (real)(o1 >> 8) * real(0x1p-24 * kHalfPi);
+  const uint32_t rm = max(max(o2 & 0xffffu, o2 >> 16), o3 & 0xffffu);
+  const real r = (real)rm * real(0x1p-16);
+  const real sn = sin_quarter(phi), cs = sin_quarter(real(kHalfPi) - phi);
+  const real rs = r * fast_sqrt_pos(real(1.0) - z * z);  // (z <= 1 - 2^-24: the argument is positive)
+  return V3{rs * cs, rs * sn, r * z};
 }
-// Unit-ball candidates: 21 bits per coordinate, one candidate per pair of words (x, y: the top 21
-// bits of the two words; z: the 11 + 10 low bits left over).  The first block of a bounce carries
-// a candidate (words 0, 1) and EITHER the dielectric coin (word 2, 32 bits) OR, for a bounce that draws no coin, a
-// second candidate (words 2, 3); a further block carries two candidates.
-// The candidate as its three 21-bit integers (X, Y, Z) = 2^21 (x, y, z).  The rejection test of random_in_unit_sphere
-// (src/random-utils.cpp:23-29: length2 >= 1) runs on them: x*x + y*y + z*z >= 1 <=> X*X + Y*Y + Z*Z >= 2^42, and the
-// binary64 form is EXACT for these operands (each square has 42 significant bits, the sums stay below 2^44 multiples
-// of 2^-42), so the integer test takes the same decision as the reference expression bit for bit — in three
-// v_mad_u64_u32 and a compare instead of three conversions, three scalings, three multiply-adds and a compare.
-// Only the ACCEPTED candidate is converted to floating point (round 4: -6 binary64-rate instructions per candidate
-// inside the rejection loop).
-struct BallCand {
-  uint32_t x, y, z;
-};
-__device__ __forceinline__ BallCand ball_ints(uint32_t lo, uint32_t hi) {
-  return BallCand{lo >> 11, hi >> 11, (lo & 0x7ffu) | ((hi & 0x3ffu) << 11)};
-}
-__device__ __forceinline__ bool ball_outside(BallCand c) {
-  const unsigned long long n2 = (unsigned long long)c.x * c.x + (unsigned long long)c.y * c.y + (unsigned long long)c.z * c.z;
-  return (uint32_t)(n2 >> 32) >= (1u << 10);  // n2 >= 2^42
-}
-__device__ __forceinline__ V3 ball_point(BallCand c) {
-  const real s21 = real(0x1p-21);
-  return V3{(real)c.x * s21, (real)c.y * s21, (real)c.z * s21};
-}
-__device__ __forceinline__ V3 ball_from_pair(uint32_t lo, uint32_t hi) { return ball_point(ball_ints(lo, hi)); }
-// first block of a bounce: candidate (w0, w1), the coin (w2) and — for a bounce that does not use the coin — a second
-// candidate (w2, w3)
-__device__ __forceinline__ void rng_scatter_first(Rng &g, uint32_t k0, uint32_t k1, real &coin, BallCand &a, BallCand &b) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
-  coin = (real)o2 * real(0x1p-32);
-  a = ball_ints(o0, o1);
-  b = ball_ints(o2, o3);
-}
-__device__ __forceinline__ void rng_scatter2i(Rng &g, uint32_t k0, uint32_t k1, BallCand &a, BallCand &b) {
-  uint32_t o0, o1, o2, o3;
-  philox4x32(g.r, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
-  g.r += 1u;
-  a = ball_ints(o0, o1);
-  b = ball_ints(o2, o3);
+__device__ __forceinline__ real coin_from_block(uint32_t o0, uint32_t o1, uint32_t o3) {
+  return (real)(((o3 >> 16) << 16) | ((o0 & 0xffu) << 8) | (o1 & 0xffu)) * real(0x1p-32);
 }

@@ -40,47 +40,66 @@ def test_mt19937_stream_and_double_mapping():
     assert L.orc_mt_random_double(-1.0, 1.0) == want * 2.0 + -1.0
 
 
+SIN_C = [float.fromhex(h) for h in ("0x1.ffffffdb33084p-1", "-0x1.555549a9260fdp-3", "0x1.110eb1f04c8ffp-7",
+                                     "-0x1.9f6d0201a288bp-13", "0x1.5da8d4e70fe23p-19")]
+HALF_PI = 1.5707963267948966
+
+
+def sin_quarter(x):
+    """The samplers' sine polynomial, operation for operation (oracle sin_quarter, csrc/rtow_trace_rng.h): Python floats
+    are binary64 and every operation below rounds once, like the strict build's."""
+    x2 = x * x
+    return x * (SIN_C[0] + x2 * (SIN_C[1] + x2 * (SIN_C[2] + x2 * (SIN_C[3] + x2 * SIN_C[4]))))
+
+
 def test_philox_requests():
-    """A request is one Philox4x32-R block, a pure function of (seed, pixel, sample, request)."""
+    """A request is ONE Philox4x32-R block, a pure function of (seed, pixel, sample, request), and carries everything the
+    request needs (round 5: no request draws a second block).  The layouts, word by word, recomputed by hand."""
+    import math
+
     L = orc.lib()
     R = L.orc_philox_rounds()
     assert R == 7
-    a = L.orc_philox_request(42, 1000, 7, 3, 1, 0)
-    assert a == L.orc_philox_request(42, 1000, 7, 3, 1, 0) and 0.0 <= a < 1.0
-    vals = {L.orc_philox_request(42, p, s, r, 1, k)
+    a = L.orc_philox_request(42, 1000, 7, 3, 2, 0)
+    assert a == L.orc_philox_request(42, 1000, 7, 3, 2, 0) and 0.0 <= a < 1.0
+    vals = {L.orc_philox_request(42, p, s, r, 2, k)
             for p in range(4) for s in range(4) for r in range(3) for k in range(2)}
     assert len(vals) == 96
-    assert L.orc_philox_request(43, 1000, 7, 3, 1, 0) != a
+    assert L.orc_philox_request(43, 1000, 7, 3, 2, 0) != a
     # the words of the block, by hand: counter (request, sample, pixel, 0), key = seed
     out = (C.c_uint32 * 4)()
     L.orc_philox4x32((C.c_uint32 * 4)(3, 7, 1000, 0), (C.c_uint32 * 2)(42, 0), out, R)
     w = list(out)
-    # a lens-disk block after the first candidate: two candidates, 32 bits per coordinate
-    for k in range(4):
-        assert L.orc_philox_request(42, 1000, 7, 3, 1, k) == w[k] / 2.0**32
-    # first block of a sample: jitter + time, the top 21 bits of words 0..2 ...
+    # the block of a new sample: jitter + time, the top 21 bits of words 0..2 ...
     for k in range(3):
         want = (w[k] >> 11) / 2.0**21
         assert L.orc_philox_request(42, 1000, 7, 3, 0, k) == want and want < 1.0
-    # ... and the first lens-disk candidate: word 3, and the 11+11+10 low bits left in words 0..2
-    assert L.orc_philox_request(42, 1000, 7, 3, 0, 3) == w[3] / 2.0**32
+    # ... and the lens point from two 32-bit uniforms — word 3, and the 11+11+10 low bits left in words 0..2 — in polar
+    # coordinates: radius sqrt(U1), angle 2 pi U2 (the top two bits of U2: the quadrant)
     low = (w[0] & 0x7ff) | ((w[1] & 0x7ff) << 11) | ((w[2] & 0x3ff) << 22)
-    assert L.orc_philox_request(42, 1000, 7, 3, 0, 4) == low / 2.0**32
-    # unit-ball candidates: 21 bits per coordinate, one candidate per pair of words; the first block
-    # of a bounce = one candidate (words 0, 1) + EITHER the coin (word 2; a bounce that draws one) OR a second
-    # candidate (words 2, 3; every other bounce); a later block = two candidates
-    def ball(lo, hi):
-        return [(lo >> 11) / 2.0**21, (hi >> 11) / 2.0**21, ((lo & 0x7ff) | ((hi & 0x3ff) << 11)) / 2.0**21]
-    first = ball(w[0], w[1])
-    for k in range(3):
-        assert L.orc_philox_request(42, 1000, 7, 3, 2, k) == first[k]
-    assert L.orc_philox_request(42, 1000, 7, 3, 2, 3) == w[2] / 2.0**32
-    second = ball(w[2], w[3])
-    for k in range(3):
-        assert L.orc_philox_request(42, 1000, 7, 3, 2, 4 + k) == second[k]
-    later = ball(w[0], w[1]) + ball(w[2], w[3])
-    for k in range(6):
-        assert L.orc_philox_request(42, 1000, 7, 3, 3, k) == later[k]
+    rho = math.sqrt(w[3] / 2.0**32)
+    th = (low & 0x3fffffff) * (2.0**-30 * HALF_PI)
+    sn, cs = sin_quarter(th), sin_quarter(HALF_PI - th)
+    q = low >> 30
+    cx, sy = (sn, cs) if q & 1 else (cs, sn)
+    assert L.orc_philox_request(42, 1000, 7, 3, 0, 3) == rho * (-cx if q in (1, 2) else cx)
+    assert L.orc_philox_request(42, 1000, 7, 3, 0, 4) == rho * (-sy if q >= 2 else sy)
+    # the block of a bounce: z = top 24 bits of word 0, azimuth = top 24 bits of word 1, radius = the largest of three
+    # 16-bit uniforms (the halves of word 2, the low half of word 3); the coin = high half of word 3 + low bytes of 0, 1
+    z = (w[0] >> 8) / 2.0**24
+    phi = (w[1] >> 8) * (2.0**-24 * HALF_PI)
+    r = max(w[2] & 0xffff, w[2] >> 16, w[3] & 0xffff) / 2.0**16
+    sn, cs = sin_quarter(phi), sin_quarter(HALF_PI - phi)
+    rs = r * math.sqrt(1.0 - z * z)
+    for k, want in enumerate((rs * cs, rs * sn, r * z)):
+        assert L.orc_philox_request(42, 1000, 7, 3, 2, k) == want
+    coin = (((w[3] >> 16) << 16) | ((w[0] & 0xff) << 8) | (w[1] & 0xff)) / 2.0**32
+    assert L.orc_philox_request(42, 1000, 7, 3, 2, 3) == coin and 0.0 <= coin < 1.0
+    # the polynomial is a sine to 7e-9 on the whole quarter turn, and sin^2 + cos^2 stays 1 to 2e-8
+    xs = np.linspace(0.0, HALF_PI, 20001)
+    sp = np.array([sin_quarter(float(x)) for x in xs])
+    assert np.abs(sp - np.sin(xs)).max() < 7e-9
+    assert np.abs(sp**2 + sp[::-1] ** 2 - 1.0).max() < 2e-8
     # reduced-round blocks differ from the 10-round ones (the KAT test pins the round function)
     out10 = (C.c_uint32 * 4)()
     L.orc_philox4x32((C.c_uint32 * 4)(3, 7, 1000, 0), (C.c_uint32 * 2)(42, 0), out10, 10)
@@ -257,40 +276,60 @@ def test_t3_philox_vs_mt19937_rmse_against_two_independent_mt_runs(kind):
     assert np.all(d_phi < 0.5), (d_phi, d_ref)
 
 
-def test_unit_ball_candidates_are_uniform_per_coordinate():
-    """The 21-bit unit-ball mapping (csrc/rtow_trace_rng.h ball_from_pair, oracle PhiloxDraw): x and
-    y are the top 21 bits of two Philox words, z is assembled from the 11 + 10 LOW bits left over.
-    Each coordinate must be uniform on [0, 1) at every bit, z's low-order assembly included, and the
-    three must be uncorrelated — checked on 200,000 candidates of the first scatter block (kind 2)
-    and of the later blocks (kind 3, two candidates per block)."""
+def _ks_two_sample(a, b):
+    """Kolmogorov-Smirnov distance of two samples and its 0.1 % critical value."""
+    a, b = np.sort(a), np.sort(b)
+    allv = np.concatenate([a, b])
+    d = np.abs(np.searchsorted(a, allv, side="right") / len(a) - np.searchsorted(b, allv, side="right") / len(b)).max()
+    return d, 1.95 * np.sqrt((len(a) + len(b)) / (len(a) * len(b)))
+
+
+def test_direct_samplers_have_the_distributions_of_the_reference_rejection_loops():
+    """The Philox policy draws random_in_unit_sphere() and random_in_unit_disk() DIRECTLY, one block per request (oracle
+    PhiloxDraw overloads, csrc/rtow_trace_rng.h); the reference draws them by rejection (src/random-utils.cpp:23-41: a
+    point of [0,1)^3 inside the unit ball — the positive octant, returned un-normalised as the "unit vector" — and a
+    point of [-1,1)^2 inside the unit disk).  Same distributions: checked here against the reference's own loops run on
+    numpy's generator — every coordinate's marginal, the radius, and products that would show a dependence — by
+    two-sample Kolmogorov-Smirnov tests at the 0.1 % level on 100,000 points each, plus the moments that have closed
+    forms and the independence of the coin from the point it comes with."""
     L = orc.lib()
-    n = 50_000
-    cols = []
-    for kind, ks in ((2, (0, 1, 2)), (3, (0, 1, 2)), (3, (3, 4, 5))):
-        v = np.array([[L.orc_philox_request(7, p, p % 13, 1 + p % 3, kind, k) for k in ks] for p in range(n)])
-        cols.append(v)
-    v = np.concatenate(cols)  # 150,000 x 3
-    assert v.min() >= 0.0 and v.max() < 1.0
-    q = np.round(v * 2**21).astype(np.int64)
-    assert np.array_equal(q / 2**21, v)  # exactly 21 bits per coordinate
-    m = len(v)
-    for c in range(3):
-        # mean and variance of U[0,1): 1/2 +- 5 sigma, 1/12
-        assert abs(v[:, c].mean() - 0.5) < 5 * np.sqrt(1 / 12 / m), (c, v[:, c].mean())
-        assert abs(v[:, c].var() - 1 / 12) < 0.002
-        # every one of the 21 bits is a fair coin (5 sigma)
-        for bit in range(21):
-            ones = ((q[:, c] >> bit) & 1).mean()
-            assert abs(ones - 0.5) < 5 * 0.5 / np.sqrt(m), (c, bit, ones)
-        # 64-bin chi-square (63 dof: mean 63, sd 11.2)
-        hist = np.bincount((v[:, c] * 64).astype(int), minlength=64)
-        chi = ((hist - m / 64) ** 2 / (m / 64)).sum()
-        assert chi < 63 + 6 * 11.3, (c, chi)
-    cc = np.corrcoef(v.T)
-    assert np.abs(cc[np.triu_indices(3, 1)]).max() < 5 / np.sqrt(m)
-    # acceptance rate of the rejection loop: volume of the unit ball's positive octant, pi/6
-    acc = (np.sum(v * v, axis=1) < 1.0).mean()
-    assert abs(acc - np.pi / 6) < 5 * np.sqrt(0.25 / m)
+    n = 100_000
+    ball = np.array([[L.orc_philox_request(7, p, p % 13, 1 + p % 3, 2, k) for k in range(4)] for p in range(n)])
+    coin, ball = ball[:, 3], ball[:, :3]
+    disk = np.array([[L.orc_philox_request(7, p, p % 13, 0, 0, k) for k in (3, 4)] for p in range(n)])
+    rng = np.random.default_rng(12345)
+    c = rng.random((3 * n, 3))
+    ref_ball = c[(c * c).sum(axis=1) < 1.0][:n]  # src/random-utils.cpp:23-29
+    c = rng.random((3 * n, 2)) * 2.0 - 1.0
+    ref_disk = c[(c * c).sum(axis=1) < 1.0][:n]  # :34-41
+    assert len(ref_ball) == n and len(ref_disk) == n
+    # inside the ball / the disk, in the positive octant
+    assert (ball >= 0.0).all() and ((ball * ball).sum(axis=1) < 1.0).all()
+    assert ((disk * disk).sum(axis=1) < 1.0).all() and (disk.min(axis=0) < -0.99).all() and (disk.max(axis=0) > 0.99).all()
+    for k in range(3):
+        d, crit = _ks_two_sample(ball[:, k], ref_ball[:, k])
+        assert d < crit, ("ball coordinate", k, d, crit)
+    for k in range(2):
+        d, crit = _ks_two_sample(disk[:, k], ref_disk[:, k])
+        assert d < crit, ("disk coordinate", k, d, crit)
+    for name, f in (("radius", lambda v: np.sqrt((v * v).sum(axis=1))), ("xy", lambda v: v[:, 0] * v[:, 1]),
+                    ("yz", lambda v: v[:, 1] * v[:, -1]), ("x+y", lambda v: v[:, 0] + v[:, 1])):
+        d, crit = _ks_two_sample(f(ball), f(ref_ball))
+        assert d < crit, ("ball", name, d, crit)
+        d, crit = _ks_two_sample(f(disk), f(ref_disk))
+        assert d < crit, ("disk", name, d, crit)
+    # closed forms: E[x] = 3/8 per coordinate and E[r] = 3/4 in the octant ball; E[r] = 2/3 and E[x] = 0 on the disk
+    m = n
+    assert np.abs(ball.mean(axis=0) - 0.375).max() < 5 * 0.25 / np.sqrt(m)
+    assert abs(np.sqrt((ball * ball).sum(axis=1)).mean() - 0.75) < 5 * 0.2 / np.sqrt(m)
+    assert np.abs(disk.mean(axis=0)).max() < 5 * 0.5 / np.sqrt(m)
+    assert abs(np.sqrt((disk * disk).sum(axis=1)).mean() - 2.0 / 3.0) < 5 * 0.24 / np.sqrt(m)
+    # the dielectric coin: uniform, and uncorrelated with the point that shares its block
+    assert 0.0 <= coin.min() and coin.max() < 1.0 and abs(coin.mean() - 0.5) < 5 * np.sqrt(1 / 12 / m)
+    hist = np.bincount((coin * 64).astype(int), minlength=64)
+    assert ((hist - m / 64) ** 2 / (m / 64)).sum() < 63 + 6 * 11.3
+    for k in range(3):
+        assert abs(np.corrcoef(coin, ball[:, k])[0, 1]) < 5 / np.sqrt(m)
 
 
 def test_stream_ranges_and_accumulation_are_bit_identical_to_one_call():
