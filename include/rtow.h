@@ -140,8 +140,11 @@ typedef struct rtow_scene_t {
  * sample order into its own partial image, and the partial images are added in
  * run order.  Effective spp = samples_per_pixel / nstreams * nstreams.
  *
- * Random numbers are counter-based: draw d of sample s of pixel p (global
- * row-major index, top row first) is a Philox4x32-7 block keyed by `seed`; the image
+ * Random numbers are counter-based: request r of sample s of pixel p (global
+ * row-major index, top row first) is ONE Philox4x32-7 block keyed by `seed` — request 0 the
+ * sample's pixel jitter, shutter time and lens point, request 1 + b everything bounce b
+ * draws (the lens point and the scatter's point of the unit ball are sampled directly, with
+ * the distributions of the reference's rejection loops, src/random-utils.cpp:23-41); the image
  * therefore does not depend on nranks, tile_rows or on which lane traced what. */
 typedef struct rtow_config_t {
   int32_t image_width;

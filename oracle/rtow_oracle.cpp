@@ -19,9 +19,12 @@
 //   PhiloxDraw— the device path's counter-based stream.  Random numbers are drawn
 //               in REQUESTS, one Philox4x32-7 block each, counter (r, s, p, 0), key =
 //               seed, a pure function of (seed, pixel p, sample s, request r):
-//               pixel jitter + shutter time share one block, every disk candidate
-//               and every unit-ball candidate takes one, and the dielectric coin
-//               rides in the spare word of the bounce's first unit-ball candidate.
+//               request 0 of a sample = pixel jitter, shutter time and the lens point,
+//               request 1 + b = bounce b's point of the unit ball and its dielectric coin.
+//               Under this policy the lens point and the "unit vector" are drawn DIRECTLY from
+//               their block (same distributions as the reference's rejection loops, which
+//               MtGlobal keeps: see struct PhiloxDraw and the overloads of
+//               random_in_unit_disk / random_in_unit_sphere).
 
 #include "rtow_oracle.h"
 

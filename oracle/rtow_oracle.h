@@ -72,8 +72,8 @@ uint64_t orc_raylog_count(void);
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4], int rounds);
 int orc_philox_rounds(void);
-/* value k of request `request`; kind 0 = jitter (u, v, time), 1 = disk (y, x),
- * 2 = scatter candidate (x, y, z, coin) */
+/* value k of request `request`: kind 0 = the block of a new sample (k = 0, 1 jitter; 2 shutter time; 3, 4 the lens
+ * point x, y), kind 2 = the block of a bounce (k = 0..2 the point of the unit ball; 3 the dielectric coin) */
 double orc_philox_request(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t request, int kind,
                           int k);
 double orc_mt_random_double(double a, double b);
