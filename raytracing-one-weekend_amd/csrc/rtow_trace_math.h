@@ -41,7 +41,7 @@ __device__ __forceinline__ V3 anyv3() { return V3{anyv(real(0)), anyv(real(0)), 
 // window: lowest), it lets the memory requests leave first and fills the wait with the arithmetic of the others.
 // Round 4, C2: +3.9 % (every other placement that was tried — a constant priority, the reverse order, priority by path
 // depth — measured the same as none or worse).  Scheduling only: the image cannot change.
-constexpr int kPrioRng = 0, kPrioStage = 2, kPrioLeaf = 3;
+constexpr int kPrioRng = 0, kPrioSetup = 1, kPrioStage = 2, kPrioLeaf = 3;
 template <int P>
 __device__ __forceinline__ void stage_prio() {
 #ifndef RTOW_NO_STAGE_PRIO
