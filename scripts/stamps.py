@@ -43,7 +43,8 @@ print(f"wave trips {trips}, step-loop iterations per trip {iters/max(trips,1):.1
 if out[45] or out[46]:
     print(f"GRID: step-loop iterations that only camera rays needed {out[45]/max(iters,1)*100:.1f} % of all; leaf phases only camera rays "
           f"needed {out[46]/max(phases,1)*100:.1f} % (the most a separate treatment of primary rays could take out of the walk)")
-print(f"Philox block evaluations per trip (wave level, new-ray stage): {out[44]/max(trips,1):.2f}; lanes per rejection-loop trip {out[36]/max(out[44]-trips,1):.1f}")
+print(f"Philox block evaluations per trip (wave level, new-ray stage): {out[44]/max(trips,1):.2f} (one per request since the direct samplers of round 5; "
+      f"with the rejection loops of rounds 1-5a: 3.35, of which 2.35 for 7.4 lanes each, profiles/r05_stamps.log)")
 nw = 4096.0
 print(f"wave end times (ms after first wave start): mean {out[4]/nw/1e5:.3f}  min {out[5]/1e5:.3f}  max {out[6]/1e5:.3f};  queue seen empty (mean over waves) {out[7]/nw/1e5:.3f}")
 
