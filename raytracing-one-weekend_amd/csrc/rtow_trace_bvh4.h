@@ -240,6 +240,10 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
   uint32_t q0 = kRefNone, q1 = kRefNone;  // queued leaves, oldest first
   uint32_t trips = 0u;                    // wave-uniform
 
+  // An image staged whole: every node step is a chain of LDS round trips (stack, planes, child words) — the walk issues at
+  // the cell lists' priority, ahead of the other waves' new-ray arithmetic (round 5: suzanne +1.2 %; a mesh whose nodes
+  // come from L2 loses 1 % with it and stays at the stage priority)
+  if constexpr (FULL) stage_prio<kPrioLeaf>();
   for (;;) {
     if constexpr (ST) {
       stamps.iters += 1;
@@ -272,11 +276,13 @@ __device__ __forceinline__ Closest closest_hit_bvh4(const Bvh4Reader<FULL> &im, 
       if (suspend) {
         w_cur = cur;  // kRefNone for the lanes that are done
         w_sa = sa;
+        if constexpr (FULL) stage_prio<kPrioStage>();
         return best;
       }
       if (!any_walking && !__any(q0 != kRefNone)) break;
     }
   }
   w_cur = kRefNone;
+  if constexpr (FULL) stage_prio<kPrioStage>();
   return best;
 }
