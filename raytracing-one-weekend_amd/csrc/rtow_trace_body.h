@@ -714,6 +714,29 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       if (__ballot(do_regen || do_scat) != 0ull) stamps.blocks += 1;
     }
     V3 dirbase = anyv3();  // bounce: direction before the fuzz term
+    // Both samplers need the sine and cosine of an angle of the first quadrant and one square root (rtow_trace_rng.h):
+    // evaluated ONCE for the camera and the scatter lanes together — the same operations on the same values as in
+    // lens_from_block / ball_from_block (which the state-machine kernel's camera_ray / scatter_dir call as they are), at
+    // twice the lane density: +0.7 % on the cover scene at 500 spp, +1.3 % on the moving cover, +0.6 % on suzanne
+    real s_ang = anyv(real(0)), s_arg = anyv(real(0)), s_z = anyv(real(0));
+    uint32_t s_b = anyv(0u);
+    if (do_regen) {
+      s_b = (o0 & 0x7ffu) | ((o1 & 0x7ffu) << 11) | ((o2 & 0x3ffu) << 22);
+      s_ang = (real)(s_b & 0x3fffffffu) * real(0x1p-30 * kHalfPi);
+      s_arg = (real)o3 * real(0x1p-32);
+    }
+    if (do_scat) {
+      s_z = (real)(o0 >> 8) * real(0x1p-24);
+      s_ang = (real)(o1 >> 8) * real(0x1p-24 * kHalfPi);
+      s_arg = real(1.0) - s_z * s_z;
+    }
+    real s_sn = anyv(real(0)), s_cs = anyv(real(0)), s_sq = anyv(real(0));
+    if (do_regen || do_scat) {
+      opaque(s_ang);  // (rtow_trace_rng.h: the angle as a rounded product, here as in the helpers)
+      s_sn = sin_quarter(s_ang);
+      s_cs = sin_quarter(real(kHalfPi) - s_ang);
+      s_sq = fast_sqrt(s_arg);
+    }
     if (do_scat) {
       if (kind == 2) {
         const real ir = m_ir;
@@ -762,7 +785,12 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
 #endif
       const real lens = cm[18], ct0 = cm[19], ct1 = cm[20];
       real px, py;  // random_in_unit_disk (src/common-model.cpp:157)
-      lens_from_block(o0, o1, o2, o3, px, py);
+      {  // (lens_from_block's last step: the quadrant)
+        const uint32_t q = s_b >> 30;
+        const real cx = (q & 1u) ? s_sn : s_cs, sy = (q & 1u) ? s_cs : s_sn;
+        px = s_sq * ((q == 1u || q == 2u) ? -cx : cx);
+        py = s_sq * (q >= 2u ? -sy : sy);
+      }
       const real rdx = lens * px, rdy = lens * py;
       const V3 offset = V3{cm[3], cm[4], cm[5]} * rdx + V3{cm[6], cm[7], cm[8]} * rdy;
       const V3 from = V3{cm[0], cm[1], cm[2]} + offset;
@@ -781,7 +809,10 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
       bool absorbed = false;
       // (the new direction is written over the old one in both branches; an absorbed path — black, src/render.cpp:120 —
       // starts a new sample in the next trip and never reads it)
-      const V3 rnd = ball_from_block(o0, o1, o2, o3);  // random_unit_vector() (src/common-model.cpp:16,26,58)
+      // random_unit_vector() (src/common-model.cpp:16,26,58): ball_from_block's last step — radius times direction
+      const real s_r = (real)max(max(o2 & 0xffffu, o2 >> 16), o3 & 0xffffu) * real(0x1p-16);
+      const real s_rs = s_r * s_sq;
+      const V3 rnd = V3{s_rs * s_cs, s_rs * s_sn, s_r * s_z};
       if (kind == 0) {
         absorbed = rabs(normal.x - rnd.x) < real(1e-8) && rabs(normal.y - rnd.y) < real(1e-8) &&
                    rabs(normal.z - rnd.z) < real(1e-8);

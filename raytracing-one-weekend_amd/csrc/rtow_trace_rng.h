@@ -65,6 +65,12 @@ __device__ __forceinline__ real sin_quarter(real x) {
                     x2 * (real(0x1.110eb1f04c8ffp-7) + x2 * (real(-0x1.9f6d0201a288bp-13) + x2 * real(0x1.5da8d4e70fe23p-19)))));
 }
 constexpr double kHalfPi = 1.5707963267948966;  // the binary64 nearest pi / 2
+// The samplers' angle is a product (bits x pi/2 x 2^-k) and its complement pi/2 - angle feeds the cosine: a fast build
+// would fuse that subtraction with the product where the compiler sees both (these helpers) and not where the angle
+// arrives through a merge of two kinds of lanes (the trip kernels' shared evaluation, rtow_trace_body.h) — and the trip
+// kernels and the state machine must draw the SAME numbers.  An empty asm statement makes the product a value the
+// subtraction cannot reach into; no instruction.
+__device__ __forceinline__ void opaque(real &x) { asm volatile("" : "+v"(x)); }
 
 // First block of a sample (request 0): pixel jitter and shutter time, 21 bits each (the top bits of words 0..2), and the
 // two 32-bit uniforms of the lens point: word 3, and the 11 + 11 + 10 low bits left over in words 0..2.
@@ -79,7 +85,8 @@ __device__ __forceinline__ void jitter_from_block(uint32_t o0, uint32_t o1, uint
 __device__ __forceinline__ void lens_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, real &px, real &py) {
   const uint32_t b = (o0 & 0x7ffu) | ((o1 & 0x7ffu) << 11) | ((o2 & 0x3ffu) << 22);
   const real rho = fast_sqrt((real)o3 * real(0x1p-32));
-  const real th = (real)(b & 0x3fffffffu) * real(0x1p-30 * kHalfPi);
+  real th = (real)(b & 0x3fffffffu) * real(0x1p-30 * kHalfPi);
+  opaque(th);  // (the angle as a ROUNDED product: see opaque())
   const real sn = sin_quarter(th), cs = sin_quarter(real(kHalfPi) - th);
   const uint32_t q = b >> 30;
   const real cx = (q & 1u) ? sn : cs, sy = (q & 1u) ? cs : sn;
@@ -93,7 +100,8 @@ __device__ __forceinline__ void lens_from_block(uint32_t o0, uint32_t o1, uint32
 // "random_unit_vector" (:31-33)
 __device__ __forceinline__ V3 ball_from_block(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
   const real z = (real)(o0 >> 8) * real(0x1p-24);
-  const real phi = (real)(o1 >> 8) * real(0x1p-24 * kHalfPi);
+  real phi = (real)(o1 >> 8) * real(0x1p-24 * kHalfPi);
+  opaque(phi);
   const uint32_t rm = max(max(o2 & 0xffffu, o2 >> 16), o3 & 0xffffu);
   const real r = (real)rm * real(0x1p-16);
   const real sn = sin_quarter(phi), cs = sin_quarter(real(kHalfPi) - phi);
