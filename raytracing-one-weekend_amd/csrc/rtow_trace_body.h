@@ -208,9 +208,8 @@ __device__ __forceinline__ ItemPos decode_item(const RTOW_CONST TraceParams *kp,
 }
 
 // Camera::get_ray for sample (g.pixel, g.sample) of pixel (column j, global row gi): pixel jitter,
-// lens disk, ray (src/render.cpp:158-159, src/common-model.cpp:156-167; disk sample: y draws first,
-// random-utils.cpp:36).  The first lens candidate comes with the jitter block; every further block
-// carries two.
+// lens point, ray (src/render.cpp:158-159, src/common-model.cpp:156-167), all from the sample's one block
+// (rtow_trace_rng.h).  The stand-alone form of the new-ray stage's camera half, used by the state-machine kernel.
 __device__ __forceinline__ void camera_ray(const TraceParams &P, Rng &g, uint32_t k0, uint32_t k1, uint32_t j,
                                            uint32_t gi, V3 &ro, V3 &rd, real &rtime) {
   g.r = 0u;
@@ -239,7 +238,8 @@ __device__ __forceinline__ void camera_ray(const TraceParams &P, Rng &g, uint32_
 }
 
 // Material::scatter (src/common-model.cpp:13-62) for a hit with shading normal `normal`: the new
-// direction, or absorbed.  The first unit-ball candidate of the bounce comes with the dielectric coin.
+// direction, or absorbed — point of the unit ball and dielectric coin from the bounce's one block (rtow_trace_rng.h).
+// The stand-alone form of the new-ray stage's scatter half, used by the state-machine kernel.
 __device__ __forceinline__ bool scatter_dir(Rng &g, uint32_t k0, uint32_t k1, int kind, real m_fuzz, real m_ir, V3 rd,
                                             V3 normal, bool front, V3 &dir) {
   uint32_t o0, o1, o2, o3;
@@ -572,12 +572,11 @@ __global__ void __launch_bounds__(KERNEL >= 2 && KERNEL <= 4 ? 1024 : 256)
     // ---- new rays ------------------------------------------------------------------------------------
     // Two kinds of lanes need a new ray before the walk: those starting a sample (pixel jitter +
     // Camera::get_ray, src/render.cpp:158-159, src/common-model.cpp:156-167) and those whose previous
-    // segment ended in a hit (Material::scatter, src/common-model.cpp:13-62).  Both draw one Philox
-    // block and then, while their candidate lies outside the unit disk / unit ball, further blocks.
-    // They draw TOGETHER: one block evaluation serves both kinds of lanes, and the rejection loop runs
-    // max(lens, ball) trips instead of lens + ball — a wave used to spend ~6 block evaluations per trip on
-    // ~1.4 needed per lane.  Every lane still consumes exactly its own requests in its own order
-    // (counter = (request, sample, pixel)), so nothing changes in the image.
+    // segment ended in a hit (Material::scatter, src/common-model.cpp:13-62).  Both draw exactly one Philox
+    // block, and they draw it TOGETHER: one block evaluation serves both kinds of lanes, and so does the one
+    // evaluation of what their two samplers share (sine, cosine, square root).  Every lane consumes exactly its own
+    // requests in its own order (counter = (request, sample, pixel)), so the image does not depend on who shares a wave
+    // with whom.  (Rounds 1-5a ran the reference's rejection loops here: ~6, later 3.4 block evaluations per trip.)
     const bool do_regen = live && need_sample;
     const bool do_scat = live && pending_hit;
     // (read only by the lanes of `do_scat`, here and in the two scatter blocks below: for every other lane the value

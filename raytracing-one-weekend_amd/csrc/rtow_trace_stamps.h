@@ -14,7 +14,7 @@ struct Stamps {
   bool tail = false;
   unsigned long long lt[RG_COUNT] = {0, 0, 0, 0, 0};    // the same, weighted by the lanes the region worked for
   unsigned long long iters = 0, trips = 0, phases = 0;  // wave-level loop counts
-  unsigned long long blocks = 0, block_lanes = 0;       // Philox block evaluations of the new-ray stage / lanes in its rejection trips
+  unsigned long long blocks = 0, block_lanes = 0;       // Philox block evaluations of the new-ray stage (one per trip) / unused since the rejection loops went
   unsigned long long step_lanes = 0, leaf_lanes = 0;    // lanes stepping per step-loop iteration / testing per leaf phase
   unsigned long long iters_cam = 0, phases_cam = 0;     // GRID: step iterations / leaf phases that only camera rays needed
   unsigned long long primary = 0;                       // lanes of this wave whose ray is a camera ray (set by the caller)
