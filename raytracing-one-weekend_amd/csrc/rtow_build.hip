@@ -512,65 +512,84 @@ __global__ void __launch_bounds__(kSahBinBlock)
     }
   }
 }
-// one thread per node of the level: the split, the children, the next level's work list; resets the node's accumulators
+// One WAVE per node of the level: the split (lane = axis x bin: the 45 candidate splits are evaluated side by side, the
+// sums over the bins to the left and to the right of a split by scans inside each axis' sixteen lanes), then — lane 0 —
+// the children and the next level's work list; resets the node's accumulators.  (One THREAD per node looped over 3 x 16
+// bins of 7 words twice and reset 336 words: 56 us per level whatever the level's size, 1.35 ms of the 96,800-triangle
+// mesh's 5.3 ms.)  The same minima, maxima, integer sums and products as the serial loop, ties to the lower axis and
+// bin as there (= the lower lane): the same tree.
 __global__ void k_sah_split(int level, int force_median, const int32_t *list, int32_t *list_next, uint32_t *cnt, int32_t *rank,
                             uint32_t *cb, uint32_t *bin, int32_t *split, int32_t *child_l, int32_t *child_r, int32_t *first,
                             int32_t *last, int32_t *parent_int, int32_t *parent_leaf) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= cnt[level]) return;
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = (int)(threadIdx.x & 63u);
+  if (t >= cnt[level]) return;  // (wave-uniform)
   const int nd = list[t];
   const int lo = first[nd], hi = last[nd], size = hi - lo + 1;
   int best_axis = -1, best_bin = 0, best_nl = size / 2;
-  float best_cost = INFINITY;
-  for (int a = 0; a < 3 && !force_median; ++a) {
-    const float cmin = unordered(cb[(size_t)t * 6 + a]), cmax = unordered(cb[(size_t)t * 6 + 3 + a]);
-    if (!(cmax > cmin)) continue;
-    const uint32_t *B = bin + ((size_t)t * 3 + a) * kSahBins * 7;
-    // suffix areas and counts: right side = bins b + 1 .. 15
-    float r_area[kSahBins];
-    uint32_t r_cnt[kSahBins];
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    uint32_t c = 0;
-    for (int b = kSahBins - 1; b >= 1; --b) {
-      if (B[b * 7] != 0u) {
-        c += B[b * 7];
-        for (int k = 0; k < 3; ++k) {
-          mn[k] = fminf(mn[k], unordered(B[b * 7 + 1 + k]));
-          mx[k] = fmaxf(mx[k], unordered(B[b * 7 + 4 + k]));
-        }
-      }
-      const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
-      r_area[b] = c ? dx * dy + dy * dz + dz * dx : 0.f;
-      r_cnt[b] = c;
-    }
-    for (int k = 0; k < 3; ++k) mn[k] = INFINITY, mx[k] = -INFINITY;
-    c = 0;
-    for (int b = 0; b < kSahBins - 1; ++b) {  // split after bin b
-      if (B[b * 7] != 0u) {
-        c += B[b * 7];
-        for (int k = 0; k < 3; ++k) {
-          mn[k] = fminf(mn[k], unordered(B[b * 7 + 1 + k]));
-          mx[k] = fmaxf(mx[k], unordered(B[b * 7 + 4 + k]));
-        }
-      }
-      if (c == 0u || r_cnt[b + 1] == 0u) continue;
-      const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
-      const float cost = (dx * dy + dy * dz + dz * dx) * (float)c + r_area[b + 1] * (float)r_cnt[b + 1];
-      if (cost < best_cost) {  // ties: the lower axis, the lower bin
-        best_cost = cost;
-        best_axis = a;
-        best_bin = b;
-        best_nl = (int)c;
-      }
-    }
-  }
   if (!force_median) {
+    const int a = lane >> 4, b = lane & 15;
+    const bool on = lane < 48;
+    float cmin = 0.f, cmax = 0.f;
+    if (on) cmin = unordered(cb[(size_t)t * 6 + a]), cmax = unordered(cb[(size_t)t * 6 + 3 + a]);
+    // this lane's bin: count and box (identities when the bin is empty, as the serial loop skipped it)
+    uint32_t c = 0u;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (on) {
+      const uint32_t *B = bin + (((size_t)t * 3 + a) * kSahBins + b) * 7;
+      c = B[0];
+      if (c != 0u)
+        for (int k = 0; k < 3; ++k) mn[k] = unordered(B[1 + k]), mx[k] = unordered(B[4 + k]);
+    }
+    // inclusive scans over the axis' sixteen lanes: bins 0 .. b (left of the split after bin b) and bins b .. 15
+    uint32_t cl = c, cr = c;
+    float lmn[3] = {mn[0], mn[1], mn[2]}, lmx[3] = {mx[0], mx[1], mx[2]};
+    float rmn[3] = {mn[0], mn[1], mn[2]}, rmx[3] = {mx[0], mx[1], mx[2]};
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t ocl = __shfl_up(cl, off, 16), ocr = __shfl_down(cr, off, 16);
+      float omn[3], omx[3], pmn[3], pmx[3];
+      for (int k = 0; k < 3; ++k) {
+        omn[k] = __shfl_up(lmn[k], off, 16), omx[k] = __shfl_up(lmx[k], off, 16);
+        pmn[k] = __shfl_down(rmn[k], off, 16), pmx[k] = __shfl_down(rmx[k], off, 16);
+      }
+      if (b >= off) {
+        cl += ocl;
+        for (int k = 0; k < 3; ++k) lmn[k] = fminf(lmn[k], omn[k]), lmx[k] = fmaxf(lmx[k], omx[k]);
+      }
+      if (b + off < 16) {
+        cr += ocr;
+        for (int k = 0; k < 3; ++k) rmn[k] = fminf(rmn[k], pmn[k]), rmx[k] = fmaxf(rmx[k], pmx[k]);
+      }
+    }
+    // the right side of the split after bin b is bins b + 1 .. 15: the inclusive suffix of the next lane
+    const uint32_t crx = __shfl_down(cr, 1, 16);
+    float xmn[3], xmx[3];
+    for (int k = 0; k < 3; ++k) xmn[k] = __shfl_down(rmn[k], 1, 16), xmx[k] = __shfl_down(rmx[k], 1, 16);
+    float cost = INFINITY;
+    if (on && cmax > cmin && b < kSahBins - 1 && cl != 0u && crx != 0u) {
+      const float dx = lmx[0] - lmn[0], dy = lmx[1] - lmn[1], dz = lmx[2] - lmn[2];
+      const float ex = xmx[0] - xmn[0], ey = xmx[1] - xmn[1], ez = xmx[2] - xmn[2];
+      const float r_area = ex * ey + ey * ez + ez * ex;
+      cost = (dx * dy + dy * dz + dz * dx) * (float)cl + r_area * (float)crx;
+    }
+    // the cheapest split; among equals the lower axis, then the lower bin: the lower lane
+    float bc = cost;
+    int bl = lane;
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float oc = __shfl_xor(bc, off);
+      const int ol = __shfl_xor(bl, off);
+      if (oc < bc || (oc == bc && ol < bl)) bc = oc, bl = ol;
+    }
+    const uint32_t nl_best = __shfl(cl, bl);
+    if (bc < INFINITY) best_axis = bl >> 4, best_bin = bl & 15, best_nl = (int)nl_best;
+    // the node's accumulators back to their identities (k_sah_bin of the next level adds into them)
     uint32_t *B0 = bin + (size_t)t * 48 * 7;
-    for (int k = 0; k < 48 * 7; ++k) {
+    for (int k = lane; k < 48 * 7; k += 64) {
       const int f = k % 7;
       B0[k] = f == 0 ? 0u : (f < 4 ? 0xffffffffu : 0u);
     }
   }
+  if (lane != 0) return;
   int32_t *sp = split + (size_t)t * 4;
   sp[0] = best_axis;
   sp[1] = best_bin;
@@ -1060,7 +1079,7 @@ int lbvh_build(const double *sph, const double *sph_r, const double *mov, const 
       const int in = level & 1, out = in ^ 1;
       // a level holds at most min(2^level, n / 2) nodes of two or more primitives
       const long long most = level < 30 ? std::min<long long>(1ll << level, n / 2 + 1) : (long long)(n / 2 + 1);
-      const int Gn = (int)((most + B - 1) / B);
+      const unsigned Gn = (unsigned)((most * 64 + B - 1) / B);  // (k_sah_split: one wave per node)
       const int force_median = level >= kSahMedianFrom ? 1 : 0;
       if (!force_median) {
         hipLaunchKernelGGL(k_sah_cb, dim3(G), dim3(B), 0, st, n, s->sh_item[in], s->sh_node[in], s->sh_rank, s->pbox, s->sh_cb);
